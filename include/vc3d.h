@@ -1,0 +1,129 @@
+/* vc3d.h -- C ABI of libvc3d.so: the MI355X (gfx950) kernels of the 3D-ResNet hot path.
+ *
+ * The reference (bfshi/Video-Classification) has no FFI: its hot path is the torch.nn
+ * calls inside lib/models/backbone.py.  Each entry point below replaces one of those
+ * calls (3D-inflated) and cites it.  A binding only needs ctypes/cffi:
+ * plain pointers, ints and floats; no torch types cross this boundary.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative code on error; vc_last_error()
+ *    returns the thread-local message.  Nothing throws across the boundary.
+ *  - all pointers are DEVICE pointers owned by the caller.  The library allocates
+ *    nothing, holds no state, never synchronises and launches on `stream`
+ *    (a hipStream_t passed as void*; NULL = the default stream).
+ *  - activations are channels-last bf16: [N][T][H][W][C]; C is a multiple of 64
+ *    (the stem's 3-channel clip goes through vc_stem_pack_input instead).
+ *  - conv weights (bf16) are [Cout][kt][kh][kw][Cin] for forward / wgrad and
+ *    [Cin][kt][kh][kw][Cout] for dgrad; vc_pack_weight makes both from the fp32 master
+ *    (which is torch's channels_last_3d storage of a [Cout][Cin][kt][kh][kw] parameter).
+ *  - "stats"/"sums" buffers are float [VC_STAT_REPLICAS][2][C], zeroed by the caller
+ *    before the kernel that accumulates into them.
+ *  - "bn params" are float [4][C]: mean, invstd, scale = gamma*invstd, shift = beta-mean*scale.
+ */
+#ifndef VC3D_H
+#define VC3D_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC_STAT_REPLICAS 32
+#define VC_ABI_VERSION 1
+
+typedef struct vc_conv3d_desc {
+    int32_t N, Ci, Ti, Hi, Wi; /* input  [N][Ti][Hi][Wi][Ci] */
+    int32_t Co;                /* output channels            */
+    int32_t kt, kh, kw;        /* kernel                     */
+    int32_t st, sh, sw;        /* stride                     */
+    int32_t pt, ph, pw;        /* zero padding               */
+} vc_conv3d_desc;
+
+typedef struct vc_pool3d_desc {
+    int32_t N, C, T, H, W;
+    int32_t kt, kh, kw, st, sh, sw, pt, ph, pw;
+} vc_pool3d_desc;
+
+const char* vc_last_error(void);
+int vc_abi_version(void);
+
+/* ---- Conv3d (bf16 MFMA implicit GEMM).  Replaces nn.Conv2d at
+ * reference lib/models/backbone.py:19-20 (conv3x3), :70-76 (Bottleneck 1x1/3x3/1x1),
+ * :131-132 (downsample 1x1) -- forward, and autograd's dgrad/wgrad of the same calls
+ * (reference lib/core/function.py:81 loss.backward()). kt*kh*kw <= 32. */
+int vc_conv3d_out_dims(const vc_conv3d_desc* d, int32_t* To, int32_t* Ho, int32_t* Wo);
+int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y,
+                  float* bn_stats /* nullable: fused sum / sum-of-squares of y */, void* stream);
+int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                    int accumulate /* dx += instead of dx = */, void* stream);
+int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy,
+                    float* dw /* fp32 [Co][kt][kh][kw][Ci], += */, void* stream);
+int vc_pack_weight(const float* w_master, void* w_fwd, void* w_dgrad /* nullable */, int32_t Co,
+                   int32_t taps, int32_t Ci, void* stream);
+
+/* ---- Stem: 7x7x7, 3 -> Co (multiple of 64), stride (1,2,2), pad 3.  Replaces
+ * reference lib/models/backbone.py:112-113,145.  The clip [N][3][T][H][W] (fp32 or bf16,
+ * H and W even) is packed once into a zero-padded space-to-depth bf16 source
+ * [N][T+6][H/2+3][W/2+3][12]; the weight into [Co][1344]. The stem has no dgrad. */
+size_t vc_stem_packed_input_elems(int32_t N, int32_t T, int32_t H, int32_t W);
+int vc_stem_pack_input(const void* x, int32_t x_is_bf16, void* xs, int32_t N, int32_t T, int32_t H,
+                       int32_t W, void* stream);
+int vc_stem_pack_weight(const float* w_master /* [Co][7][7][7][3] */, void* ws, int32_t Co, void* stream);
+int vc_stem_fwd(const void* xs, const void* ws, void* y /* [N][T][H/2][W/2][Co] */, float* bn_stats,
+                int32_t N, int32_t T, int32_t H, int32_t W, int32_t Co, void* stream);
+int vc_stem_wgrad(const void* xs, const void* dy, float* dws /* fp32 [Co][1344], += */, int32_t N,
+                  int32_t T, int32_t H, int32_t W, int32_t Co, void* stream);
+int vc_stem_unpack_wgrad(const float* dws, float* dw_master /* [Co][7][7][7][3], += */, int32_t Co,
+                         void* stream);
+
+/* ---- BatchNorm3d (+ReLU, +residual).  Replaces nn.BatchNorm2d / nn.ReLU / `out += residual`
+ * at reference lib/models/backbone.py:39-42,50-51,54,59-60 (BasicBlock), :71-79,87-101
+ * (Bottleneck), :114-115,146-147 (stem), :133 (downsample); BN_MOMENTUM :13. */
+int vc_bn_stats(const void* y, float* sums, int64_t rows, int32_t C, void* stream);
+int vc_bn_finalize(const float* stats, int32_t C, float count, const float* gamma, const float* beta,
+                   float* running_mean /* nullable */, float* running_var, float momentum, float eps,
+                   float* params, void* stream);
+int vc_bn_eval_params(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* params, void* stream);
+int vc_bn_apply(const void* y, const float* params, const void* residual /* nullable */, void* out,
+                int64_t elems, int32_t C, int32_t relu, void* stream);
+/* mask: 0 none; 1 gradient passes where aux (saved post-activation output) > 0;
+ *       2 where y*scale+shift > 0 (recomputed) */
+int vc_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums,
+                     int64_t rows, int32_t C, int32_t mask, void* stream);
+int vc_bn_bwd_finalize(const float* sums, int32_t C, float count, float* coef /* [2][C] */,
+                       float* dgamma /* += nullable */, float* dbeta /* += nullable */, void* stream);
+int vc_bn_bwd_apply(const void* y, const void* dz, const void* aux, const float* params,
+                    const float* coef, void* dy, void* g_out /* nullable: masked dz */, int64_t elems,
+                    int32_t C, int32_t mask, void* stream);
+int vc_add(const void* a, const void* b, void* out, int64_t elems, void* stream);
+
+/* ---- Pooling.  Replaces nn.MaxPool2d(3,2,1) at reference lib/models/backbone.py:116,148 and
+ * nn.AvgPool2d(7)+Flatten at :122-125,155 (global average in 3D). */
+int vc_pool3d_out_dims(const vc_pool3d_desc* d, int32_t* To, int32_t* Ho, int32_t* Wo);
+int vc_maxpool3d_fwd(const vc_pool3d_desc* d, const void* y,
+                     const float* bn_params /* nullable: apply BN+ReLU to y first */, void* out,
+                     uint8_t* argmax, void* stream);
+int vc_maxpool3d_bwd(const vc_pool3d_desc* d, const void* dout, const uint8_t* argmax, void* din,
+                     void* stream);
+int vc_gavgpool_fwd(const void* in, float* out, int32_t N, int32_t S, int32_t C, void* stream);
+int vc_gavgpool_bwd(const float* dfeat, void* din, int32_t N, int32_t S, int32_t C, void* stream);
+
+/* ---- Classifier head (fp32).  Replaces nn.Linear at reference lib/models/model.py:24,38. */
+int vc_linear_fwd(const float* feat, const float* W, const float* bias, float* out, int32_t N,
+                  int32_t F, int32_t K, void* stream);
+int vc_linear_bwd(const float* dlogits, const float* feat, const float* W, float* dfeat /* nullable */,
+                  float* dW /* += nullable */, float* db /* += nullable */, int32_t N, int32_t F,
+                  int32_t K, void* stream);
+
+/* ---- Layout helpers at the API edge (NCTHW <-> NTHWC). */
+int vc_ncthw_to_nthwc(const void* in, int32_t in_is_bf16, void* out, int32_t N, int32_t C, int64_t S,
+                      void* stream);
+int vc_nthwc_to_ncthw(const void* in, void* out, int32_t out_is_bf16, int32_t N, int32_t C, int64_t S,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VC3D_H */

@@ -1,0 +1,302 @@
+"""GPU parity tests, op level: every HIP kernel behind the C ABI against stock torch fp32 on
+the CPU (the oracle's arithmetic), on the same seeded inputs.
+
+Tolerances (stated per north_star: fp32 reference vs bf16 MFMA with fp32 accumulation):
+inputs are rounded to bf16 before both paths, so the only differences are summation order
+and the final bf16 rounding of the output (2^-9 relative per element).
+  bf16 outputs : rel-L2 <= 4e-3, max |err| <= 2e-2 * max|ref|
+  fp32 outputs : rel-L2 <= 1e-3
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_BF16 = 4e-3
+TOL_F32 = 1e-3
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def rel_l2(a, b):
+    a = a.double().flatten()
+    b = b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def to_nthwc_dev(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(torch.bfloat16).cuda()
+
+
+def from_nthwc(y):
+    return y.float().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def cl3d_param(w):
+    """fp32 weight on the GPU stored channels_last_3d, as the product's parameters are."""
+    return w.cuda().contiguous(memory_format=torch.channels_last_3d)
+
+
+CONV_CASES = [
+    # N, Ci, T, H, W, Co, k, s, p
+    (2, 64, 4, 6, 5, 64, 3, 1, 1),
+    (2, 64, 5, 9, 7, 128, 3, 2, 1),
+    (1, 128, 4, 8, 8, 128, 3, 1, 1),
+    (3, 128, 3, 7, 7, 256, 3, 2, 1),
+    (2, 64, 4, 8, 8, 128, 1, 2, 0),
+    (2, 256, 2, 5, 5, 64, 1, 1, 0),
+    (2, 64, 8, 14, 14, 64, 3, 1, 1),   # several 256-row tiles
+    (2, 64, 1, 6, 6, 64, 3, 1, 1),     # T = 1 (centre-tap regime)
+    (2, 64, 1, 7, 7, 128, 3, 2, 1),
+    (1, 512, 1, 4, 4, 512, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_fwd_dgrad_wgrad(case):
+    _need_gpu()
+    from vc3d import ops
+    N, Ci, T, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = bf16_round(torch.randn(N, Ci, T, H, W, generator=g))
+    w = bf16_round(torch.randn(Co, Ci, k, k, k, generator=g) * (2.0 / (Ci * k ** 3)) ** 0.5)
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y_ref = F.conv3d(x, w, stride=s, padding=p)
+    dy = bf16_round(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+
+    d = ops.conv_desc(N, Ci, T, H, W, Co, k, s, p)
+    wf, wd = ops.pack_weight(cl3d_param(w.detach()))
+    xd = to_nthwc_dev(x.detach())
+    stats = ops.new_stats(Co, "cuda")
+    y = ops.conv3d_fwd(d, xd, wf, stats=stats)
+    torch.cuda.synchronize()
+    y_h = from_nthwc(y)
+    assert rel_l2(y_h, y_ref.detach()) <= TOL_BF16
+    assert float((y_h - y_ref.detach()).abs().max()) <= 2e-2 * float(y_ref.abs().max())
+    # fused BN statistics (sum, sum of squares over N,T,H,W per channel)
+    st = stats.sum(0).cpu()
+    ref_s = y_ref.detach().sum(dim=(0, 2, 3, 4))
+    ref_q = (y_ref.detach() ** 2).sum(dim=(0, 2, 3, 4))
+    assert float((st[0] - ref_s).abs().max()) <= 1e-3 * float(ref_q.max().sqrt() * (y_ref[0, 0].numel() * N) ** 0.5)
+    assert rel_l2(st[1], ref_q) <= TOL_F32
+
+    dyd = to_nthwc_dev(dy)
+    dx = ops.conv3d_dgrad(d, dyd, wd)
+    torch.cuda.synchronize()
+    assert rel_l2(from_nthwc(dx), x.grad) <= TOL_BF16
+    # accumulate form: dx2 = dx + dgrad
+    dx2 = dx.clone()
+    ops.conv3d_dgrad(d, dyd, wd, out=dx2, accumulate=True)
+    torch.cuda.synchronize()
+    assert rel_l2(from_nthwc(dx2), 2 * x.grad) <= 2 * TOL_BF16
+
+    dw = torch.zeros(Co, k, k, k, Ci, dtype=torch.float32, device="cuda")
+    ops.conv3d_wgrad(d, xd, dyd, dw)
+    torch.cuda.synchronize()
+    dw_h = dw.cpu().permute(0, 4, 1, 2, 3)
+    assert rel_l2(dw_h, w.grad) <= TOL_F32
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 16, 16), (1, 1, 12, 20), (3, 5, 8, 8)])
+def test_stem_fwd_wgrad(shape):
+    _need_gpu()
+    from vc3d import ops
+    N, T, H, W = shape
+    Co = 64
+    g = torch.Generator().manual_seed(7 + N)
+    x = bf16_round(torch.randn(N, 3, T, H, W, generator=g))
+    w = bf16_round(torch.randn(Co, 3, 7, 7, 7, generator=g) * (2.0 / (64 * 343)) ** 0.5 * 4)
+    w.requires_grad_(True)
+    y_ref = F.conv3d(x, w, stride=(1, 2, 2), padding=3)
+    dy = bf16_round(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy)
+
+    xs = ops.stem_pack_input(x.cuda())
+    ws = ops.stem_pack_weight(cl3d_param(w.detach()))
+    stats = ops.new_stats(Co, "cuda")
+    y = ops.stem_fwd(xs, ws, N, T, H, W, Co, stats=stats)
+    torch.cuda.synchronize()
+    assert rel_l2(from_nthwc(y), y_ref.detach()) <= TOL_BF16
+    st = stats.sum(0).cpu()
+    assert rel_l2(st[1], (y_ref.detach() ** 2).sum(dim=(0, 2, 3, 4))) <= TOL_F32
+
+    dwm = torch.zeros(Co, 7, 7, 7, 3, dtype=torch.float32, device="cuda")
+    ops.stem_wgrad(xs, to_nthwc_dev(dy), N, T, H, W, Co, dwm)
+    torch.cuda.synchronize()
+    assert rel_l2(dwm.cpu().permute(0, 4, 1, 2, 3), w.grad) <= TOL_F32
+    # bf16 clip input gives the same packed source
+    xs2 = ops.stem_pack_input(x.cuda().to(torch.bfloat16))
+    assert torch.equal(xs, xs2)
+
+
+@pytest.mark.parametrize("C,shape", [(64, (2, 4, 6, 6)), (128, (3, 2, 5, 5)), (512, (4, 1, 4, 4)), (2048, (2, 1, 2, 2))])
+@pytest.mark.parametrize("mode", ["plain", "relu", "res_relu"])
+def test_batchnorm_fwd_bwd(C, shape, mode):
+    _need_gpu()
+    from vc3d import ops
+    N, T, H, W = shape
+    g = torch.Generator().manual_seed(C + N)
+    y = bf16_round(torch.randn(N, C, T, H, W, generator=g) * 2 + 0.5)
+    res = bf16_round(torch.randn(N, C, T, H, W, generator=g))
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.1
+    y.requires_grad_(True)
+    res.requires_grad_(True)
+    bn = torch.nn.BatchNorm3d(C, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    bn.train()
+    z_ref = bn(y)
+    if mode == "res_relu":
+        z_ref = z_ref + res
+    if mode != "plain":
+        z_ref = torch.relu(z_ref)
+    dz = bf16_round(torch.randn(z_ref.shape, generator=g))
+    z_ref.backward(dz)
+
+    yd = to_nthwc_dev(y.detach())
+    rows = N * T * H * W
+    sums = ops.bn_stats(yd, C)
+    rm = torch.zeros(C, device="cuda")
+    rv = torch.ones(C, device="cuda")
+    params = ops.bn_finalize(sums, rows, gamma.cuda(), beta.cuda(), rm, rv, 0.1, 1e-5)
+    resd = to_nthwc_dev(res.detach()) if mode == "res_relu" else None
+    z = ops.bn_apply(yd, params, C, residual=resd, relu=(mode != "plain"))
+    torch.cuda.synchronize()
+    assert rel_l2(from_nthwc(z), z_ref.detach()) <= TOL_BF16
+    assert rel_l2(rm.cpu(), bn.running_mean) <= 1e-4
+    assert rel_l2(rv.cpu(), bn.running_var) <= 1e-4
+
+    dgamma = torch.zeros(C, device="cuda")
+    dbeta = torch.zeros(C, device="cuda")
+    mask = 0 if mode == "plain" else 1
+    dy, gm = ops.bn_bwd(yd, to_nthwc_dev(dz), params, C, dgamma, dbeta, mask=mask, aux=z if mask else None,
+                        want_g=True)
+    torch.cuda.synchronize()
+    assert rel_l2(from_nthwc(dy), y.grad) <= 2 * TOL_BF16
+    assert rel_l2(dgamma.cpu(), bn.weight.grad) <= 5e-3
+    assert rel_l2(dbeta.cpu(), bn.bias.grad) <= 5e-3
+    if mode == "res_relu":
+        assert rel_l2(from_nthwc(gm), res.grad) <= TOL_BF16
+    if mode == "relu":
+        # recomputed mask (y*scale+shift > 0) must agree with the saved-output mask
+        dg2 = torch.zeros(C, device="cuda")
+        db2 = torch.zeros(C, device="cuda")
+        dy2, _ = ops.bn_bwd(yd, to_nthwc_dev(dz), params, C, dg2, db2, mask=2)
+        torch.cuda.synchronize()
+        assert rel_l2(from_nthwc(dy2), y.grad) <= 2 * TOL_BF16
+
+
+def test_bn_eval_params():
+    _need_gpu()
+    from vc3d import ops
+    C = 64
+    g = torch.Generator().manual_seed(3)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    p = ops.bn_eval_params(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-5).cpu()
+    scale = gamma / torch.sqrt(rv + 1e-5)
+    assert torch.allclose(p[2], scale, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(p[3], beta - rm * scale, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 4, 8, 8), (1, 64, 5, 7, 9), (2, 64, 1, 6, 6)])
+@pytest.mark.parametrize("fused_bn", [False, True])
+def test_maxpool_fwd_bwd(shape, fused_bn):
+    _need_gpu()
+    from vc3d import ops
+    N, C, T, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    y = bf16_round(torch.randn(N, C, T, H, W, generator=g))
+    d = ops.pool_desc(N, C, T, H, W, 3, 2, 1)
+    yd = to_nthwc_dev(y)
+    if fused_bn:
+        scale = torch.rand(C, generator=g) + 0.5
+        shift = torch.randn(C, generator=g) * 0.2
+        params = torch.stack([torch.zeros(C), torch.ones(C), scale, shift]).cuda()
+        a = bf16_round(torch.relu(y * scale.view(1, C, 1, 1, 1) + shift.view(1, C, 1, 1, 1)))
+    else:
+        params = None
+        a = y
+    a = a.clone().requires_grad_(True)
+    p_ref = F.max_pool3d(a, 3, 2, 1)
+    dp = bf16_round(torch.randn(p_ref.shape, generator=g))
+    p_ref.backward(dp)
+    out, idx = ops.maxpool3d_fwd(d, yd, params)
+    din = ops.maxpool3d_bwd(d, to_nthwc_dev(dp), idx)
+    torch.cuda.synchronize()
+    assert torch.equal(from_nthwc(out), p_ref.detach())
+    if fused_bn:
+        # ties among equal (often zero) activations may pick another arg-max; where the activation is
+        # positive and unique the gradient must match.  Compare after masking by (a > 0).
+        m = (a.detach() > 0).float()
+        assert rel_l2(from_nthwc(din) * m, a.grad * m) <= 2e-2
+    else:
+        assert rel_l2(from_nthwc(din), a.grad) <= TOL_BF16
+
+
+def test_avgpool_linear():
+    _need_gpu()
+    from vc3d import ops
+    N, C, S, K = 5, 512, 16, 101
+    g = torch.Generator().manual_seed(5)
+    x = bf16_round(torch.randn(N, S, C, generator=g))
+    feat = ops.gavgpool_fwd(x.to(torch.bfloat16).cuda(), N, S, C)
+    assert torch.allclose(feat.cpu(), x.mean(1), rtol=1e-5, atol=1e-5)
+    Wt = torch.randn(K, C, generator=g) * 0.05
+    b = torch.randn(K, generator=g)
+    f = feat.cpu().clone().requires_grad_(True)
+    Wr = Wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    lo_ref = F.linear(f, Wr, br)
+    dl = torch.randn(N, K, generator=g)
+    lo_ref.backward(dl)
+    lo = ops.linear_fwd(feat, Wt.cuda(), b.cuda())
+    assert torch.allclose(lo.cpu(), lo_ref.detach(), rtol=1e-4, atol=1e-4)
+    dW = torch.zeros(K, C, device="cuda")
+    db = torch.zeros(K, device="cuda")
+    dfeat = ops.linear_bwd(dl.cuda(), feat, Wt.cuda(), dW, db)
+    assert torch.allclose(dfeat.cpu(), f.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(dW.cpu(), Wr.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(db.cpu(), br.grad, rtol=1e-4, atol=1e-4)
+    din = ops.gavgpool_bwd(dfeat, N, S, C, (N, S, C))
+    ref = (f.grad / S).view(N, 1, C).expand(N, S, C)
+    assert rel_l2(din.float().cpu(), ref) <= TOL_BF16
+
+
+def test_layout_roundtrip_and_add():
+    _need_gpu()
+    from vc3d import ops
+    g = torch.Generator().manual_seed(9)
+    x = bf16_round(torch.randn(2, 64, 3, 4, 5, generator=g))
+    xd = ops.ncthw_to_nthwc(x.cuda())
+    assert torch.equal(xd.float().cpu(), x.permute(0, 2, 3, 4, 1))
+    back = ops.nthwc_to_ncthw(xd)
+    assert torch.equal(back.cpu(), x)
+    s = ops.add(xd, xd)
+    assert torch.equal(s.float().cpu(), bf16_round(2 * x).permute(0, 2, 3, 4, 1))
+
+
+def test_shape_errors_are_loud():
+    _need_gpu()
+    from vc3d import ops, capi
+    d = ops.conv_desc(1, 48, 2, 4, 4, 64, 3, 1, 1)  # Ci not a multiple of 64
+    x = torch.zeros(1, 2, 4, 4, 48, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(64, 27 * 48, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(capi.Vc3dError):
+        ops.conv3d_fwd(d, x, w)
+    with pytest.raises(capi.Vc3dError):
+        ops.stem_pack_input(torch.zeros(1, 3, 2, 5, 4, device="cuda"))  # odd H
+    with pytest.raises(capi.Vc3dError):
+        ops.bn_apply(torch.zeros(8, 64), torch.zeros(4, 64), 64)  # CPU tensors: no fallback

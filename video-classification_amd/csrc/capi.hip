@@ -1,0 +1,426 @@
+// extern "C" entry points of libvc3d.so (declared in include/vc3d.h): validate shapes on the
+// host, build the gather descriptions and launch.  Nothing here allocates or synchronises.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vc3d.h"
+#include "common.h"
+#include "elementwise.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void vc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define VC_REQUIRE(cond, ...)         \
+    do {                              \
+        if (!(cond)) {                \
+            vc_set_error(__VA_ARGS__); \
+            return -2;                \
+        }                             \
+    } while (0)
+
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+static bool pow2_channels(int C) { return C >= 64 && C <= 2048 && (C & (C - 1)) == 0; }
+
+static int conv_dims(const vc_conv3d_desc* d, int& To, int& Ho, int& Wo) {
+    VC_REQUIRE(d != nullptr, "null descriptor");
+    VC_REQUIRE(d->N > 0 && d->Ci > 0 && d->Co > 0 && d->Ti > 0 && d->Hi > 0 && d->Wi > 0, "conv3d: bad dims");
+    VC_REQUIRE(d->kt > 0 && d->kh > 0 && d->kw > 0 && d->st > 0 && d->sh > 0 && d->sw > 0, "conv3d: bad kernel/stride");
+    VC_REQUIRE(d->pt >= 0 && d->ph >= 0 && d->pw >= 0, "conv3d: bad padding");
+    To = (d->Ti + 2 * d->pt - d->kt) / d->st + 1;
+    Ho = (d->Hi + 2 * d->ph - d->kh) / d->sh + 1;
+    Wo = (d->Wi + 2 * d->pw - d->kw) / d->sw + 1;
+    VC_REQUIRE(To > 0 && Ho > 0 && Wo > 0 && d->Ti + 2 * d->pt >= d->kt && d->Hi + 2 * d->ph >= d->kh &&
+                   d->Wi + 2 * d->pw >= d->kw,
+               "conv3d: empty output");
+    return 0;
+}
+
+static int conv_check(const vc_conv3d_desc* d, int& To, int& Ho, int& Wo) {
+    int rc = conv_dims(d, To, Ho, Wo);
+    if (rc) return rc;
+    VC_REQUIRE(d->Ci % 64 == 0 && d->Co % 64 == 0, "conv3d: Ci=%d and Co=%d must be multiples of 64", d->Ci, d->Co);
+    VC_REQUIRE(d->kt * d->kh * d->kw <= 32, "conv3d: at most 32 taps (got %d)", d->kt * d->kh * d->kw);
+    const long long in_e = (long long)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
+    const long long out_e = (long long)d->N * To * Ho * Wo * d->Co;
+    VC_REQUIRE(in_e < (1ll << 31) && out_e < (1ll << 31),
+               "conv3d: tensor exceeds 2^31 elements; split the batch (in=%lld out=%lld)", in_e, out_e);
+    return 0;
+}
+
+extern "C" {
+
+const char* vc_last_error(void) { return g_err; }
+int vc_abi_version(void) { return VC_ABI_VERSION; }
+
+int vc_conv3d_out_dims(const vc_conv3d_desc* d, int32_t* To, int32_t* Ho, int32_t* Wo) {
+    int a, b, c;
+    int rc = conv_dims(d, a, b, c);
+    if (rc) return rc;
+    *To = a;
+    *Ho = b;
+    *Wo = c;
+    return 0;
+}
+
+int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, void* stream) {
+    int To, Ho, Wo;
+    int rc = conv_check(d, To, Ho, Wo);
+    if (rc) return rc;
+    VC_REQUIRE(x && w && y, "conv3d_fwd: null pointer");
+    VcIgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.src = (const bf16*)x;
+    p.wgt = (const bf16*)w;
+    p.out = (bf16*)y;
+    p.stats = bn_stats;
+    p.M = d->N * To * Ho * Wo;
+    p.Ta = To, p.Ha = Ho, p.Wa = Wo;
+    p.dWa = vc_make_fastdiv(Wo), p.dHa = vc_make_fastdiv(Ho), p.dTa = vc_make_fastdiv(To);
+    p.Ts = d->Ti, p.Hs = d->Hi, p.Ws = d->Wi, p.Cs = d->Ci;
+    p.st = d->st, p.sh = d->sh, p.sw = d->sw;
+    p.ntaps = d->kt * d->kh * d->kw;
+    p.Kw = p.ntaps * d->Ci;
+    p.Cn = d->Co;
+    p.out_w = d->Co, p.out_h = Wo * d->Co, p.out_t = Ho * Wo * d->Co, p.out_n = To * Ho * Wo * d->Co, p.out_base = 0;
+    p.accumulate = 0;
+    int i = 0;
+    for (int a = 0; a < d->kt; ++a)
+        for (int b = 0; b < d->kh; ++b)
+            for (int c = 0; c < d->kw; ++c, ++i) {
+                VcTap& t = p.taps[i];
+                t.ot = (short)(a - d->pt), t.oh = (short)(b - d->ph), t.ow = (short)(c - d->pw);
+                t.src_off = ((t.ot * d->Hi + t.oh) * d->Wi + t.ow) * d->Ci;
+                t.wk_off = i * d->Ci;
+            }
+    return vc_launch_igemm(p, 0, S(stream));
+}
+
+static inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+static inline int posmod(int a, int b) { return ((a % b) + b) % b; }
+
+int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                    void* stream) {
+    int To, Ho, Wo;
+    int rc = conv_check(d, To, Ho, Wo);
+    if (rc) return rc;
+    VC_REQUIRE(dy && w_dgrad && dx, "conv3d_dgrad: null pointer");
+    const int ntaps_all = d->kt * d->kh * d->kw;
+    // a parity class with no contributing tap gets zeros
+    bool need_zero = false;
+    if (!accumulate) {
+        for (int rt = 0; rt < d->st && !need_zero; ++rt)
+            for (int rh = 0; rh < d->sh && !need_zero; ++rh)
+                for (int rw = 0; rw < d->sw && !need_zero; ++rw) {
+                    int cnt = 0;
+                    for (int a = 0; a < d->kt; ++a)
+                        for (int b = 0; b < d->kh; ++b)
+                            for (int c = 0; c < d->kw; ++c)
+                                if (posmod(rt + d->pt - a, d->st) == 0 && posmod(rh + d->ph - b, d->sh) == 0 &&
+                                    posmod(rw + d->pw - c, d->sw) == 0)
+                                    ++cnt;
+                    if (cnt == 0) need_zero = true;
+                }
+        if (need_zero) {
+            if (hipMemsetAsync(dx, 0, (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci * 2, S(stream)) != hipSuccess) {
+                vc_set_error("conv3d_dgrad: memset failed");
+                return -1;
+            }
+        }
+    }
+    for (int rt = 0; rt < d->st; ++rt)
+        for (int rh = 0; rh < d->sh; ++rh)
+            for (int rw = 0; rw < d->sw; ++rw) {
+                VcIgemmParams p;
+                memset(&p, 0, sizeof(p));
+                p.src = (const bf16*)dy;
+                p.wgt = (const bf16*)w_dgrad;
+                p.out = (bf16*)dx;
+                p.stats = nullptr;
+                p.Ta = (d->Ti - rt + d->st - 1) / d->st;
+                p.Ha = (d->Hi - rh + d->sh - 1) / d->sh;
+                p.Wa = (d->Wi - rw + d->sw - 1) / d->sw;
+                if (p.Ta <= 0 || p.Ha <= 0 || p.Wa <= 0) continue;
+                p.M = d->N * p.Ta * p.Ha * p.Wa;
+                p.dWa = vc_make_fastdiv(p.Wa), p.dHa = vc_make_fastdiv(p.Ha), p.dTa = vc_make_fastdiv(p.Ta);
+                p.Ts = To, p.Hs = Ho, p.Ws = Wo, p.Cs = d->Co;
+                p.st = p.sh = p.sw = 1;
+                p.Kw = ntaps_all * d->Co;
+                p.Cn = d->Ci;
+                p.out_w = d->sw * d->Ci;
+                p.out_h = d->sh * d->Wi * d->Ci;
+                p.out_t = d->st * d->Hi * d->Wi * d->Ci;
+                p.out_n = d->Ti * d->Hi * d->Wi * d->Ci;
+                p.out_base = ((rt * d->Hi + rh) * d->Wi + rw) * d->Ci;
+                p.accumulate = accumulate;
+                int n = 0, i = 0;
+                for (int a = 0; a < d->kt; ++a)
+                    for (int b = 0; b < d->kh; ++b)
+                        for (int c = 0; c < d->kw; ++c, ++i) {
+                            const int nt = rt + d->pt - a, nh = rh + d->ph - b, nw = rw + d->pw - c;
+                            if (posmod(nt, d->st) || posmod(nh, d->sh) || posmod(nw, d->sw)) continue;
+                            VcTap& t = p.taps[n++];
+                            t.ot = (short)floordiv(nt, d->st), t.oh = (short)floordiv(nh, d->sh),
+                            t.ow = (short)floordiv(nw, d->sw);
+                            t.src_off = ((t.ot * Ho + t.oh) * Wo + t.ow) * d->Co;
+                            t.wk_off = i * d->Co;
+                        }
+                p.ntaps = n;
+                if (n == 0) continue;
+                rc = vc_launch_igemm(p, 0, S(stream));
+                if (rc) return rc;
+            }
+    return 0;
+}
+
+int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, float* dw, void* stream) {
+    int To, Ho, Wo;
+    int rc = conv_check(d, To, Ho, Wo);
+    if (rc) return rc;
+    VC_REQUIRE(x && dy && dw, "conv3d_wgrad: null pointer");
+    VcWgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16*)x;
+    p.dy = (const bf16*)dy;
+    p.dw = dw;
+    p.M = d->N * To * Ho * Wo;
+    p.Ta = To, p.Ha = Ho, p.Wa = Wo;
+    p.dWa = vc_make_fastdiv(Wo), p.dHa = vc_make_fastdiv(Ho), p.dTa = vc_make_fastdiv(To);
+    p.Ts = d->Ti, p.Hs = d->Hi, p.Ws = d->Wi, p.Cs = d->Ci;
+    p.st = d->st, p.sh = d->sh, p.sw = d->sw;
+    p.ntaps = d->kt * d->kh * d->kw;
+    p.Kw = p.ntaps * d->Ci;
+    p.Co = d->Co;
+    int i = 0;
+    for (int a = 0; a < d->kt; ++a)
+        for (int b = 0; b < d->kh; ++b)
+            for (int c = 0; c < d->kw; ++c, ++i) {
+                VcTap& t = p.taps[i];
+                t.ot = (short)(a - d->pt), t.oh = (short)(b - d->ph), t.ow = (short)(c - d->pw);
+                t.src_off = ((t.ot * d->Hi + t.oh) * d->Wi + t.ow) * d->Ci;
+                t.wk_off = i * d->Ci;
+            }
+    return vc_launch_wgrad(p, 0, S(stream));
+}
+
+int vc_pack_weight(const float* w_master, void* w_fwd, void* w_dgrad, int32_t Co, int32_t taps, int32_t Ci,
+                   void* stream) {
+    VC_REQUIRE(w_master && w_fwd && Co > 0 && taps > 0 && Ci > 0, "pack_weight: bad arguments");
+    return vc_ew_pack_weight(w_master, w_fwd, w_dgrad, Co, taps, Ci, S(stream));
+}
+
+/* ------------------------------------------------------------------ stem */
+static int stem_check(int N, int T, int H, int W, int Co) {
+    VC_REQUIRE(N > 0 && T > 0 && H > 0 && W > 0, "stem: bad dims");
+    VC_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H=%d and W=%d must be even", H, W);
+    VC_REQUIRE(Co % 64 == 0 && Co > 0, "stem: Co=%d must be a multiple of 64", Co);
+    const long long in_e = (long long)N * (T + 6) * (H / 2 + 3) * (W / 2 + 3) * 12;
+    const long long out_e = (long long)N * T * (H / 2) * (W / 2) * Co;
+    VC_REQUIRE(in_e < (1ll << 31) && out_e < (1ll << 31), "stem: tensor exceeds 2^31 elements; split the batch");
+    return 0;
+}
+
+size_t vc_stem_packed_input_elems(int32_t N, int32_t T, int32_t H, int32_t W) {
+    return (size_t)N * (T + 6) * (H / 2 + 3) * (W / 2 + 3) * 12;
+}
+
+int vc_stem_pack_input(const void* x, int32_t x_is_bf16, void* xs, int32_t N, int32_t T, int32_t H, int32_t W,
+                       void* stream) {
+    int rc = stem_check(N, T, H, W, 64);
+    if (rc) return rc;
+    VC_REQUIRE(x && xs, "stem_pack_input: null pointer");
+    return vc_ew_stem_pack_input(x, x_is_bf16, xs, N, T, H, W, S(stream));
+}
+
+int vc_stem_pack_weight(const float* w_master, void* ws, int32_t Co, void* stream) {
+    VC_REQUIRE(w_master && ws && Co > 0, "stem_pack_weight: bad arguments");
+    return vc_ew_stem_pack_weight(w_master, ws, Co, S(stream));
+}
+
+static void stem_geometry(int N, int T, int H, int W, int& M, int& Ho, int& Wo, int& Tp, int& Hp, int& Wp) {
+    Ho = H / 2, Wo = W / 2;
+    Tp = T + 6, Hp = Ho + 3, Wp = Wo + 3;
+    M = N * T * Ho * Wo;
+}
+
+int vc_stem_fwd(const void* xs, const void* ws, void* y, float* bn_stats, int32_t N, int32_t T, int32_t H, int32_t W,
+                int32_t Co, void* stream) {
+    int rc = stem_check(N, T, H, W, Co);
+    if (rc) return rc;
+    VC_REQUIRE(xs && ws && y, "stem_fwd: null pointer");
+    int M, Ho, Wo, Tp, Hp, Wp;
+    stem_geometry(N, T, H, W, M, Ho, Wo, Tp, Hp, Wp);
+    VcIgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.src = (const bf16*)xs;
+    p.wgt = (const bf16*)ws;
+    p.out = (bf16*)y;
+    p.stats = bn_stats;
+    p.M = M;
+    p.Ta = T, p.Ha = Ho, p.Wa = Wo;
+    p.dWa = vc_make_fastdiv(Wo), p.dHa = vc_make_fastdiv(Ho), p.dTa = vc_make_fastdiv(T);
+    p.Ts = Tp, p.Hs = Hp, p.Ws = Wp, p.Cs = 12;
+    p.st = p.sh = p.sw = 1;
+    p.ntaps = 0;
+    p.Kw = 1344;
+    p.Cn = Co;
+    p.out_w = Co, p.out_h = Wo * Co, p.out_t = Ho * Wo * Co, p.out_n = T * Ho * Wo * Co, p.out_base = 0;
+    return vc_launch_igemm(p, 1, S(stream));
+}
+
+int vc_stem_wgrad(const void* xs, const void* dy, float* dws, int32_t N, int32_t T, int32_t H, int32_t W, int32_t Co,
+                  void* stream) {
+    int rc = stem_check(N, T, H, W, Co);
+    if (rc) return rc;
+    VC_REQUIRE(xs && dy && dws, "stem_wgrad: null pointer");
+    int M, Ho, Wo, Tp, Hp, Wp;
+    stem_geometry(N, T, H, W, M, Ho, Wo, Tp, Hp, Wp);
+    VcWgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16*)xs;
+    p.dy = (const bf16*)dy;
+    p.dw = dws;
+    p.M = M;
+    p.Ta = T, p.Ha = Ho, p.Wa = Wo;
+    p.dWa = vc_make_fastdiv(Wo), p.dHa = vc_make_fastdiv(Ho), p.dTa = vc_make_fastdiv(T);
+    p.Ts = Tp, p.Hs = Hp, p.Ws = Wp, p.Cs = 12;
+    p.st = p.sh = p.sw = 1;
+    p.ntaps = 0;
+    p.Kw = 1344;
+    p.Co = Co;
+    return vc_launch_wgrad(p, 1, S(stream));
+}
+
+int vc_stem_unpack_wgrad(const float* dws, float* dw_master, int32_t Co, void* stream) {
+    VC_REQUIRE(dws && dw_master && Co > 0, "stem_unpack_wgrad: bad arguments");
+    return vc_ew_stem_unpack_wgrad(dws, dw_master, Co, S(stream));
+}
+
+/* ------------------------------------------------------------------ batch norm */
+int vc_bn_stats(const void* y, float* sums, int64_t rows, int32_t C, void* stream) {
+    VC_REQUIRE(y && sums && rows > 0, "bn_stats: bad arguments");
+    VC_REQUIRE(pow2_channels(C), "bn: C=%d must be a power of two in [64, 2048]", C);
+    return vc_ew_bn_stats(y, sums, rows, C, S(stream));
+}
+int vc_bn_finalize(const float* stats, int32_t C, float count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps, float* params, void* stream) {
+    VC_REQUIRE(stats && gamma && beta && params && C > 0 && count > 0, "bn_finalize: bad arguments");
+    VC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
+    return vc_ew_bn_finalize(stats, C, count, gamma, beta, running_mean, running_var, momentum, eps, params, S(stream));
+}
+int vc_bn_eval_params(int32_t C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* params, void* stream) {
+    VC_REQUIRE(gamma && beta && running_mean && running_var && params && C > 0, "bn_eval_params: bad arguments");
+    return vc_ew_bn_eval_params(C, gamma, beta, running_mean, running_var, eps, params, S(stream));
+}
+int vc_bn_apply(const void* y, const float* params, const void* residual, void* out, int64_t elems, int32_t C,
+                int32_t relu, void* stream) {
+    VC_REQUIRE(y && params && out && elems > 0, "bn_apply: bad arguments");
+    VC_REQUIRE(C % 8 == 0 && elems % C == 0, "bn_apply: C=%d must divide elems and be a multiple of 8", C);
+    return vc_ew_bn_apply(y, params, residual, out, elems, C, relu, S(stream));
+}
+int vc_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums, int64_t rows,
+                     int32_t C, int32_t mask, void* stream) {
+    VC_REQUIRE(y && dz && params && sums && rows > 0, "bn_bwd_reduce: bad arguments");
+    VC_REQUIRE(pow2_channels(C), "bn: C=%d must be a power of two in [64, 2048]", C);
+    VC_REQUIRE(mask >= 0 && mask <= 2 && (mask != 1 || aux), "bn_bwd_reduce: bad mask mode");
+    return vc_ew_bn_bwd_reduce(y, dz, aux, params, sums, rows, C, mask, S(stream));
+}
+int vc_bn_bwd_finalize(const float* sums, int32_t C, float count, float* coef, float* dgamma, float* dbeta,
+                       void* stream) {
+    VC_REQUIRE(sums && coef && C > 0 && count > 0, "bn_bwd_finalize: bad arguments");
+    return vc_ew_bn_bwd_finalize(sums, C, count, coef, dgamma, dbeta, S(stream));
+}
+int vc_bn_bwd_apply(const void* y, const void* dz, const void* aux, const float* params, const float* coef, void* dy,
+                    void* g_out, int64_t elems, int32_t C, int32_t mask, void* stream) {
+    VC_REQUIRE(y && dz && params && coef && dy && elems > 0, "bn_bwd_apply: bad arguments");
+    VC_REQUIRE(C % 8 == 0 && elems % C == 0, "bn_bwd_apply: C=%d must divide elems and be a multiple of 8", C);
+    VC_REQUIRE(mask >= 0 && mask <= 2 && (mask != 1 || aux), "bn_bwd_apply: bad mask mode");
+    return vc_ew_bn_bwd_apply(y, dz, aux, params, coef, dy, g_out, elems, C, mask, S(stream));
+}
+int vc_add(const void* a, const void* b, void* out, int64_t elems, void* stream) {
+    VC_REQUIRE(a && b && out && elems > 0 && elems % 8 == 0, "add: bad arguments");
+    return vc_ew_add(a, b, out, elems, S(stream));
+}
+
+/* ------------------------------------------------------------------ pooling */
+static int pool_geom(const vc_pool3d_desc* d, VcPoolGeom& g) {
+    VC_REQUIRE(d != nullptr, "null descriptor");
+    VC_REQUIRE(d->N > 0 && d->C > 0 && d->C % 8 == 0 && d->T > 0 && d->H > 0 && d->W > 0, "pool3d: bad dims");
+    VC_REQUIRE(d->kt > 0 && d->kh > 0 && d->kw > 0 && d->st > 0 && d->sh > 0 && d->sw > 0, "pool3d: bad kernel");
+    VC_REQUIRE(d->kt * d->kh * d->kw <= 255, "pool3d: window too large");
+    VC_REQUIRE(2 * d->pt <= d->kt && 2 * d->ph <= d->kh && 2 * d->pw <= d->kw, "pool3d: pad must be <= kernel/2");
+    g.N = d->N, g.C = d->C, g.T = d->T, g.H = d->H, g.W = d->W;
+    g.kt = d->kt, g.kh = d->kh, g.kw = d->kw, g.st = d->st, g.sh = d->sh, g.sw = d->sw;
+    g.pt = d->pt, g.ph = d->ph, g.pw = d->pw;
+    g.To = (d->T + 2 * d->pt - d->kt) / d->st + 1;
+    g.Ho = (d->H + 2 * d->ph - d->kh) / d->sh + 1;
+    g.Wo = (d->W + 2 * d->pw - d->kw) / d->sw + 1;
+    VC_REQUIRE(g.To > 0 && g.Ho > 0 && g.Wo > 0 && d->T + 2 * d->pt >= d->kt && d->H + 2 * d->ph >= d->kh &&
+                   d->W + 2 * d->pw >= d->kw,
+               "pool3d: empty output");
+    return 0;
+}
+int vc_pool3d_out_dims(const vc_pool3d_desc* d, int32_t* To, int32_t* Ho, int32_t* Wo) {
+    VcPoolGeom g;
+    int rc = pool_geom(d, g);
+    if (rc) return rc;
+    *To = g.To, *Ho = g.Ho, *Wo = g.Wo;
+    return 0;
+}
+int vc_maxpool3d_fwd(const vc_pool3d_desc* d, const void* y, const float* bn_params, void* out, uint8_t* argmax,
+                     void* stream) {
+    VcPoolGeom g;
+    int rc = pool_geom(d, g);
+    if (rc) return rc;
+    VC_REQUIRE(y && out && argmax, "maxpool3d_fwd: null pointer");
+    return vc_ew_maxpool_fwd(y, bn_params, out, argmax, g, S(stream));
+}
+int vc_maxpool3d_bwd(const vc_pool3d_desc* d, const void* dout, const uint8_t* argmax, void* din, void* stream) {
+    VcPoolGeom g;
+    int rc = pool_geom(d, g);
+    if (rc) return rc;
+    VC_REQUIRE(dout && argmax && din, "maxpool3d_bwd: null pointer");
+    return vc_ew_maxpool_bwd(dout, argmax, din, g, S(stream));
+}
+int vc_gavgpool_fwd(const void* in, float* out, int32_t N, int32_t Sp, int32_t C, void* stream) {
+    VC_REQUIRE(in && out && N > 0 && Sp > 0 && C > 0, "gavgpool_fwd: bad arguments");
+    return vc_ew_avgpool_fwd(in, out, N, Sp, C, S(stream));
+}
+int vc_gavgpool_bwd(const float* dfeat, void* din, int32_t N, int32_t Sp, int32_t C, void* stream) {
+    VC_REQUIRE(dfeat && din && N > 0 && Sp > 0 && C > 0, "gavgpool_bwd: bad arguments");
+    return vc_ew_avgpool_bwd(dfeat, din, N, Sp, C, S(stream));
+}
+
+/* ------------------------------------------------------------------ head */
+int vc_linear_fwd(const float* feat, const float* W, const float* bias, float* out, int32_t N, int32_t F, int32_t K,
+                  void* stream) {
+    VC_REQUIRE(feat && W && out && N > 0 && F > 0 && K > 0, "linear_fwd: bad arguments");
+    return vc_ew_linear_fwd(feat, W, bias, out, N, F, K, S(stream));
+}
+int vc_linear_bwd(const float* dlogits, const float* feat, const float* W, float* dfeat, float* dW, float* db,
+                  int32_t N, int32_t F, int32_t K, void* stream) {
+    VC_REQUIRE(dlogits && N > 0 && F > 0 && K > 0, "linear_bwd: bad arguments");
+    VC_REQUIRE((!dfeat || W) && (!dW || feat), "linear_bwd: missing operand");
+    return vc_ew_linear_bwd(dlogits, feat, W, dfeat, dW, db, N, F, K, S(stream));
+}
+
+/* ------------------------------------------------------------------ layout */
+int vc_ncthw_to_nthwc(const void* in, int32_t in_is_bf16, void* out, int32_t N, int32_t C, int64_t Sp, void* stream) {
+    VC_REQUIRE(in && out && N > 0 && C > 0 && Sp > 0, "ncthw_to_nthwc: bad arguments");
+    return vc_ew_ncs_to_nsc(in, in_is_bf16, out, N, C, Sp, S(stream));
+}
+int vc_nthwc_to_ncthw(const void* in, void* out, int32_t out_is_bf16, int32_t N, int32_t C, int64_t Sp, void* stream) {
+    VC_REQUIRE(in && out && N > 0 && C > 0 && Sp > 0, "nthwc_to_ncthw: bad arguments");
+    return vc_ew_nsc_to_ncs(in, out, out_is_bf16, N, C, Sp, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,38 @@
+// Launch wrappers of elementwise.hip (internal; the C ABI in capi.hip validates and forwards).
+#pragma once
+#include "common.h"
+
+struct VcPoolGeom {
+    int N, C, T, H, W;
+    int To, Ho, Wo;
+    int kt, kh, kw, st, sh, sw, pt, ph, pw;
+};
+
+int vc_ew_bn_finalize(const float* stats, int C, float count, const float* gamma, const float* beta, float* rmean,
+                      float* rvar, float momentum, float eps, float* params, hipStream_t s);
+int vc_ew_bn_eval_params(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
+                         float* params, hipStream_t s);
+int vc_ew_bn_apply(const void* y, const float* params, const void* res, void* out, long n, int C, int relu,
+                   hipStream_t s);
+int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, hipStream_t s);
+int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums, long rows,
+                        int C, int mask, hipStream_t s);
+int vc_ew_bn_bwd_finalize(const float* sums, int C, float count, float* coef, float* dgamma, float* dbeta,
+                          hipStream_t s);
+int vc_ew_bn_bwd_apply(const void* y, const void* dz, const void* aux, const float* params, const float* coef, void* dy,
+                       void* gout, long n, int C, int mask, hipStream_t s);
+int vc_ew_add(const void* a, const void* b, void* out, long n, hipStream_t s);
+int vc_ew_maxpool_fwd(const void* y, const float* params, void* out, uint8_t* idx, const VcPoolGeom& g, hipStream_t s);
+int vc_ew_maxpool_bwd(const void* dout, const uint8_t* idx, void* din, const VcPoolGeom& g, hipStream_t s);
+int vc_ew_avgpool_fwd(const void* in, float* out, int N, int S, int C, hipStream_t s);
+int vc_ew_avgpool_bwd(const float* dfeat, void* din, int N, int S, int C, hipStream_t s);
+int vc_ew_linear_fwd(const float* feat, const float* W, const float* bias, float* out, int N, int F, int K,
+                     hipStream_t s);
+int vc_ew_linear_bwd(const float* dlog, const float* feat, const float* W, float* dfeat, float* dW, float* db, int N,
+                     int F, int K, hipStream_t s);
+int vc_ew_stem_pack_input(const void* x, int x_is_bf16, void* xs, int N, int T, int H, int W, hipStream_t s);
+int vc_ew_ncs_to_nsc(const void* in, int in_is_bf16, void* out, int N, int C, long S, hipStream_t s);
+int vc_ew_nsc_to_ncs(const void* in, void* out, int out_is_bf16, int N, int C, long S, hipStream_t s);
+int vc_ew_pack_weight(const float* w, void* wf, void* wd, int Co, int taps, int Ci, hipStream_t s);
+int vc_ew_stem_pack_weight(const float* w, void* ws, int Co, hipStream_t s);
+int vc_ew_stem_unpack_wgrad(const float* dws, float* dw, int Co, hipStream_t s);

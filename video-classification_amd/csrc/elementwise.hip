@@ -1,0 +1,689 @@
+// Bandwidth-bound kernels of the 3D-ResNet path (gfx950): BatchNorm3d statistics /
+// apply / backward, ReLU and residual add, 3D max / average pooling, the classifier
+// head, layout packing and weight preparation.  Activations are channels-last (NTHWC)
+// bf16, so every kernel moves 16 bytes (8 channels) per lane and indexes its per-channel
+// parameters by (element index mod C).
+#include "common.h"
+#include "elementwise.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const bf16x8& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = bf2f(v[i]);
+}
+__device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = f2bf(f[i]);
+    return v;
+}
+
+// ------------------------------------------------------------------ BN finalize
+// stats [R][2][C] (sum, sumsq) -> params [4][C] = mean, invstd, scale, shift; running stats.
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, float count, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var, float momentum,
+                                   float eps, float* params) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < VC_STAT_REPLICAS; ++r) {
+        s += stats[(size_t)r * 2 * C + c];
+        q += stats[(size_t)r * 2 * C + C + c];
+    }
+    const float mean = s / count;
+    float var = q / count - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float invstd = rsqrtf(var + eps);
+    const float scale = gamma[c] * invstd;
+    params[c] = mean;
+    params[C + c] = invstd;
+    params[2 * C + c] = scale;
+    params[3 * C + c] = beta[c] - mean * scale;
+    if (running_mean != nullptr) {
+        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// eval mode: params from running statistics
+__global__ void bn_eval_params_kernel(int C, const float* gamma, const float* beta, const float* running_mean,
+                                      const float* running_var, float eps, float* params) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = rsqrtf(running_var[c] + eps);
+    const float scale = gamma[c] * invstd;
+    params[c] = running_mean[c];
+    params[C + c] = invstd;
+    params[2 * C + c] = scale;
+    params[3 * C + c] = beta[c] - running_mean[c] * scale;
+}
+
+// ------------------------------------------------------------------ BN apply (+res)(+relu)
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16x8* __restrict__ y, const float* __restrict__ params,
+                                                       const bf16x8* __restrict__ res, bf16x8* __restrict__ out,
+                                                       long n8, int C) {
+    const float* scale = params + 2 * C;
+    const float* shift = params + 3 * C;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const int c = (int)((i * 8) % C);
+        float f[8], r[8];
+        unpack8(y[i], f);
+        if (RES) unpack8(res[i], r);
+        const f32x4 s0 = *(const f32x4*)(scale + c), s1 = *(const f32x4*)(scale + c + 4);
+        const f32x4 b0 = *(const f32x4*)(shift + c), b1 = *(const f32x4*)(shift + c + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = f[k] * (k < 4 ? s0[k] : s1[k - 4]) + (k < 4 ? b0[k] : b1[k - 4]);
+            if (RES) v += r[k];
+            if (RELU) v = v > 0.f ? v : 0.f;
+            f[k] = v;
+        }
+        out[i] = pack8(f);
+    }
+}
+
+// ------------------------------------------------------------------ per-channel reductions
+// MODE 0: sum y, sum y^2 (standalone BN statistics)
+// MODE 1: BN backward sums: sum g, sum g*xhat with g = dz * mask
+//   MASK 0 none, 1 mask = (aux > 0) with aux the saved post-activation output,
+//        2 mask = (y*scale+shift > 0) recomputed
+// Rows are split over blocks; a block reduces its partial sums through LDS and adds them to
+// one of VC_STAT_REPLICAS copies of sums[2][C].
+template <int MODE, int MASK>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restrict__ y, const bf16x8* __restrict__ dz,
+                                                          const bf16x8* __restrict__ aux,
+                                                          const float* __restrict__ params, float* sums, long rows,
+                                                          int C, int rows_per_block) {
+    __shared__ float sm[256 * 17];
+    const int groups = C >> 3;             // 8-channel groups per row (<= 256)
+    const int rl = 256 / groups;           // row lanes per block
+    const int g = threadIdx.x % groups;
+    const int r = threadIdx.x / groups;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
+    float mean[8], invstd[8], scale[8], shift[8];
+    if (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            mean[k] = params[g * 8 + k];
+            invstd[k] = params[C + g * 8 + k];
+            scale[k] = params[2 * C + g * 8 + k];
+            shift[k] = params[3 * C + g * 8 + k];
+        }
+    }
+    const long row0 = (long)blockIdx.x * rows_per_block;
+    long row1 = row0 + rows_per_block;
+    if (row1 > rows) row1 = rows;
+    if (r < rl) {
+        for (long row = row0 + r; row < row1; row += rl) {
+            const long i = row * groups + g;
+            float f[8];
+            unpack8(y[i], f);
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    a0[k] += f[k];
+                    a1[k] += f[k] * f[k];
+                }
+            } else {
+                float d[8], m[8];
+                unpack8(dz[i], d);
+                if (MASK == 1) unpack8(aux[i], m);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float gk = d[k];
+                    if (MASK == 1) gk = m[k] > 0.f ? gk : 0.f;
+                    if (MASK == 2) gk = (f[k] * scale[k] + shift[k]) > 0.f ? gk : 0.f;
+                    a0[k] += gk;
+                    a1[k] += gk * (f[k] - mean[k]) * invstd[k];
+                }
+            }
+        }
+    }
+    // block reduce over row lanes
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sm[threadIdx.x * 17 + k] = a0[k];
+        sm[threadIdx.x * 17 + 8 + k] = a1[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        float* dst = sums + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * C;
+        for (int k = 0; k < 16; ++k) {
+            float s = 0.f;
+            for (int rr = 0; rr < rl; ++rr) s += sm[(rr * groups + threadIdx.x) * 17 + k];
+            const int c = threadIdx.x * 8 + (k & 7);
+            atomicAdd(dst + (k < 8 ? 0 : C) + c, s);
+        }
+    }
+}
+
+// BN backward finalize: sums [R][2][C] -> coef [2][C] = (sum g)/n, (sum g xhat)/n ; dgamma += sum g xhat ; dbeta += sum g
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, float count, float* coef, float* dgamma,
+                                       float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < VC_STAT_REPLICAS; ++r) {
+        s += sums[(size_t)r * 2 * C + c];
+        q += sums[(size_t)r * 2 * C + C + c];
+    }
+    coef[c] = s / count;
+    coef[C + c] = q / count;
+    if (dgamma != nullptr) dgamma[c] += q;
+    if (dbeta != nullptr) dbeta[c] += s;
+}
+
+// BN backward apply: dy = scale * (g - c1 - xhat*c2); optionally writes g (the masked
+// incoming gradient, which is also the gradient of the residual branch).
+template <int MASK, bool WRITE_G>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16x8* __restrict__ y, const bf16x8* __restrict__ dz,
+                                                           const bf16x8* __restrict__ aux,
+                                                           const float* __restrict__ params,
+                                                           const float* __restrict__ coef, bf16x8* __restrict__ dy,
+                                                           bf16x8* __restrict__ gout, long n8, int C) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const int c = (int)((i * 8) % C);
+        float f[8], d[8], m[8], o[8];
+        unpack8(y[i], f);
+        unpack8(dz[i], d);
+        if (MASK == 1) unpack8(aux[i], m);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float mean = params[c + k], invstd = params[C + c + k], scale = params[2 * C + c + k],
+                        shift = params[3 * C + c + k];
+            float gk = d[k];
+            if (MASK == 1) gk = m[k] > 0.f ? gk : 0.f;
+            if (MASK == 2) gk = (f[k] * scale + shift) > 0.f ? gk : 0.f;
+            const float xhat = (f[k] - mean) * invstd;
+            o[k] = scale * (gk - coef[c + k] - xhat * coef[C + c + k]);
+            d[k] = gk;
+        }
+        dy[i] = pack8(o);
+        if (WRITE_G) gout[i] = pack8(d);
+    }
+}
+
+// ------------------------------------------------------------------ add (bf16): out = a + b
+__global__ __launch_bounds__(256) void add_kernel(const bf16x8* __restrict__ a, const bf16x8* __restrict__ b,
+                                                  bf16x8* __restrict__ out, long n8) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        float x[8], z[8];
+        unpack8(a[i], x);
+        unpack8(b[i], z);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] += z[k];
+        out[i] = pack8(x);
+    }
+}
+
+// ------------------------------------------------------------------ max pool (fused BN apply + ReLU in front)
+// y raw [N][T][H][W][C] -> out [N][To][Ho][Wo][C] (bf16) + argmax tap index (uint8)
+template <bool BN>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16x8* __restrict__ y, const float* __restrict__ params,
+                                                          bf16x8* __restrict__ out, uint8_t* __restrict__ idx,
+                                                          VcPoolGeom g) {
+    const int groups = g.C >> 3;
+    const long total = (long)g.N * g.To * g.Ho * g.Wo * groups;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int cg = (int)(i % groups);
+        long pos = i / groups;
+        const int wo = (int)(pos % g.Wo);
+        pos /= g.Wo;
+        const int ho = (int)(pos % g.Ho);
+        pos /= g.Ho;
+        const int to = (int)(pos % g.To);
+        const int n = (int)(pos / g.To);
+        float sc[8], sh[8];
+        if (BN) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sc[k] = params[2 * g.C + cg * 8 + k];
+                sh[k] = params[3 * g.C + cg * 8 + k];
+            }
+        }
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            best[k] = -INFINITY;
+            bi[k] = 0;
+        }
+        for (int a = 0; a < g.kt; ++a) {
+            const int t = to * g.st - g.pt + a;
+            if ((unsigned)t >= (unsigned)g.T) continue;
+            for (int b = 0; b < g.kh; ++b) {
+                const int h = ho * g.sh - g.ph + b;
+                if ((unsigned)h >= (unsigned)g.H) continue;
+                for (int c = 0; c < g.kw; ++c) {
+                    const int w = wo * g.sw - g.pw + c;
+                    if ((unsigned)w >= (unsigned)g.W) continue;
+                    const long src = ((((long)n * g.T + t) * g.H + h) * g.W + w) * groups + cg;
+                    float f[8];
+                    unpack8(y[src], f);
+                    const int tap = (a * g.kh + b) * g.kw + c;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float v = f[k];
+                        if (BN) {
+                            v = v * sc[k] + sh[k];
+                            v = v > 0.f ? v : 0.f;
+                            v = bf2f(f2bf(v));  // the value a materialised activation would hold
+                        }
+                        if (v > best[k]) {
+                            best[k] = v;
+                            bi[k] = tap;
+                        }
+                    }
+                }
+            }
+        }
+        out[i] = pack8(best);
+        uint64_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) packed |= (uint64_t)(bi[k] & 0xff) << (8 * k);
+        *(uint64_t*)(idx + i * 8) = packed;
+    }
+}
+
+// gradient of max pool w.r.t. its input, gather form: every input position looks at the
+// windows that contain it and takes the pooled gradient where it was the arg-max.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16x8* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                          bf16x8* __restrict__ din, VcPoolGeom g) {
+    const int groups = g.C >> 3;
+    const long total = (long)g.N * g.T * g.H * g.W * groups;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int cg = (int)(i % groups);
+        long pos = i / groups;
+        const int w = (int)(pos % g.W);
+        pos /= g.W;
+        const int h = (int)(pos % g.H);
+        pos /= g.H;
+        const int t = (int)(pos % g.T);
+        const int n = (int)(pos / g.T);
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        // windows o with o*s - p <= i <= o*s - p + k - 1
+        const int to_lo = max(0, (t + g.pt - g.kt + g.st) / g.st), to_hi = min(g.To - 1, (t + g.pt) / g.st);
+        const int ho_lo = max(0, (h + g.ph - g.kh + g.sh) / g.sh), ho_hi = min(g.Ho - 1, (h + g.ph) / g.sh);
+        const int wo_lo = max(0, (w + g.pw - g.kw + g.sw) / g.sw), wo_hi = min(g.Wo - 1, (w + g.pw) / g.sw);
+        for (int to = to_lo; to <= to_hi; ++to)
+            for (int ho = ho_lo; ho <= ho_hi; ++ho)
+                for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                    const int tap = ((t + g.pt - to * g.st) * g.kh + (h + g.ph - ho * g.sh)) * g.kw +
+                                    (w + g.pw - wo * g.sw);
+                    const long o = ((((long)n * g.To + to) * g.Ho + ho) * g.Wo + wo) * groups + cg;
+                    const uint64_t packed = *(const uint64_t*)(idx + o * 8);
+                    float d[8];
+                    unpack8(dout[o], d);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if ((int)((packed >> (8 * k)) & 0xff) == tap) acc[k] += d[k];
+                }
+        din[i] = pack8(acc);
+    }
+}
+
+// ------------------------------------------------------------------ global average pool
+// in [N][S][C] bf16 -> out [N][C] fp32
+__global__ void avgpool_fwd_kernel(const bf16* __restrict__ in, float* __restrict__ out, int N, int S, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += bf2f(in[((size_t)n * S + k) * C + c]);
+    out[i] = s / (float)S;
+}
+// dfeat [N][C] fp32 -> din [N][S][C] bf16
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dfeat, bf16* __restrict__ din, int N, int S, int C) {
+    const long total = (long)N * S * C;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const float inv = 1.f / (float)S;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / ((long)S * C));
+        din[i] = f2bf(dfeat[(size_t)n * C + c] * inv);
+    }
+}
+
+// ------------------------------------------------------------------ classifier head (fp32)
+// one wave per output: logits[n][k] = sum_f feat[n][f] W[k][f] + b[k]
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                         int F, int K) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (o >= N * K) return;
+    const int n = o / K, k = o - n * K;
+    float s = 0.f;
+    for (int f = lane; f < F; f += 64) s += feat[(size_t)n * F + f] * W[(size_t)k * F + f];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[o] = s + (bias ? bias[k] : 0.f);
+}
+// dfeat[n][f] = sum_k dlog[n][k] W[k][f]
+__global__ void linear_bwd_data_kernel(const float* __restrict__ dlog, const float* __restrict__ W,
+                                       float* __restrict__ dfeat, int N, int F, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * F) return;
+    const int n = i / F, f = i - n * F;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += dlog[(size_t)n * K + k] * W[(size_t)k * F + f];
+    dfeat[i] = s;
+}
+// dW[k][f] += sum_n dlog[n][k] feat[n][f] ; db[k] += sum_n dlog[n][k]
+__global__ void linear_bwd_weight_kernel(const float* __restrict__ dlog, const float* __restrict__ feat,
+                                         float* __restrict__ dW, float* __restrict__ db, int N, int F, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * F) return;
+    const int k = i / F, f = i - k * F;
+    float s = 0.f, sb = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float d = dlog[(size_t)n * K + k];
+        s += d * feat[(size_t)n * F + f];
+        sb += d;
+    }
+    dW[i] += s;
+    if (f == 0 && db != nullptr) db[k] += sb;
+}
+
+// ------------------------------------------------------------------ layout
+// clip batch x [N][3][T][H][W] (fp32 or bf16) -> zero-padded space-to-depth stem source
+// xs [N][T+6][H/2+3][W/2+3][12], channel = (bh*2 + bw)*3 + c, pads: T 3/3, H' 2/1, W' 2/1
+template <typename TIN>
+__global__ __launch_bounds__(256) void stem_pack_input_kernel(const TIN* __restrict__ x, bf16* __restrict__ xs, int N, int T,
+                                                              int H, int W) {
+    const int Tp = T + 6, Hp = H / 2 + 3, Wp = W / 2 + 3;
+    const long total = (long)N * Tp * Hp * Wp;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        long pos = i;
+        const int wp = (int)(pos % Wp);
+        pos /= Wp;
+        const int hp = (int)(pos % Hp);
+        pos /= Hp;
+        const int tp = (int)(pos % Tp);
+        const int n = (int)(pos / Tp);
+        const int t = tp - 3, h2 = hp - 2, w2 = wp - 2;
+        bf16 v[12];
+        const bool in = (unsigned)t < (unsigned)T && (unsigned)h2 < (unsigned)(H / 2) && (unsigned)w2 < (unsigned)(W / 2);
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+            for (int bw = 0; bw < 2; ++bw)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float f = 0.f;
+                    if (in) f = (float)x[((((long)n * 3 + c) * T + t) * H + (2 * h2 + bh)) * W + (2 * w2 + bw)];
+                    v[(bh * 2 + bw) * 3 + c] = f2bf(f);
+                }
+        bf16x4* dst = (bf16x4*)(xs + i * 12);
+        dst[0] = (bf16x4){v[0], v[1], v[2], v[3]};
+        dst[1] = (bf16x4){v[4], v[5], v[6], v[7]};
+        dst[2] = (bf16x4){v[8], v[9], v[10], v[11]};
+    }
+}
+
+// generic NCTHW (fp32|bf16) <-> NTHWC bf16, S = T*H*W
+template <typename TIN>
+__global__ void ncs_to_nsc_kernel(const TIN* __restrict__ in, bf16* __restrict__ out, int N, int C, long S) {
+    const long total = (long)N * C * S;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const long s = (i / C) % S;
+        const long n = i / ((long)C * S);
+        out[i] = f2bf((float)in[(n * C + c) * S + s]);
+    }
+}
+template <typename TOUT>
+__global__ void nsc_to_ncs_kernel(const bf16* __restrict__ in, TOUT* __restrict__ out, int N, int C, long S) {
+    const long total = (long)N * C * S;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long s = i % S;
+        const int c = (int)((i / S) % C);
+        const long n = i / ((long)C * S);
+        out[i] = (TOUT)bf2f(in[(n * S + s) * C + c]);
+    }
+}
+
+// ------------------------------------------------------------------ weight preparation
+// master fp32 [Co][taps][Ci] -> bf16 same layout (forward / wgrad) and bf16 [Ci][taps][Co] (dgrad)
+__global__ void pack_weight_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wd, int Co,
+                                   int taps, int Ci) {
+    const long total = (long)Co * taps * Ci;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int ci = (int)(i % Ci);
+        const int tap = (int)((i / Ci) % taps);
+        const int co = (int)(i / ((long)Ci * taps));
+        const bf16 v = f2bf(w[i]);
+        wf[i] = v;
+        if (wd != nullptr) wd[((long)ci * taps + tap) * Co + co] = v;
+    }
+}
+
+// stem: master fp32 [64][7][7][7][3] -> bf16 [64][1344], K = ((kt*4 + ah)*4 + aw)*12 + (bh*2+bw)*3 + c
+// with kh = 2*ah + bh - 1, kw = 2*aw + bw - 1 (index -1 = zero column)
+__device__ __forceinline__ int stem_k_to_src(int k, int& valid) {
+    const int c = k % 3;
+    const int bw = (k / 3) & 1;
+    const int bh = (k / 6) & 1;
+    const int aw = (k / 12) & 3;
+    const int ah = (k / 48) & 3;
+    const int kt = k / 192;
+    const int kh = 2 * ah + bh - 1, kw = 2 * aw + bw - 1;
+    valid = (kh >= 0 && kw >= 0);
+    return ((kt * 7 + kh) * 7 + kw) * 3 + c;
+}
+__global__ void stem_pack_weight_kernel(const float* __restrict__ w, bf16* __restrict__ ws, int Co) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Co * 1344) return;
+    const int co = i / 1344, k = i - co * 1344;
+    int valid;
+    const int src = stem_k_to_src(k, valid);
+    ws[i] = f2bf(valid ? w[co * 1029 + src] : 0.f);
+}
+__global__ void stem_unpack_wgrad_kernel(const float* __restrict__ dws, float* __restrict__ dw, int Co) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Co * 1344) return;
+    const int co = i / 1344, k = i - co * 1344;
+    int valid;
+    const int src = stem_k_to_src(k, valid);
+    if (valid) dw[co * 1029 + src] += dws[i];
+}
+
+inline int grid_for(long n, int block = 256, int cap = 256 * 16) {
+    long g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+#define VC_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : (vc_set_error("kernel launch failed"), -1))
+
+int vc_ew_bn_finalize(const float* stats, int C, float count, const float* gamma, const float* beta, float* rmean,
+                      float* rvar, float momentum, float eps, float* params, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, C, count, gamma, beta, rmean,
+                       rvar, momentum, eps, params);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_bn_eval_params(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
+                         float* params, hipStream_t s) {
+    hipLaunchKernelGGL(bn_eval_params_kernel, dim3((C + 255) / 256), dim3(256), 0, s, C, gamma, beta, rmean, rvar, eps,
+                       params);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_bn_apply(const void* y, const float* params, const void* res, void* out, long n, int C, int relu,
+                   hipStream_t s) {
+    const long n8 = n / 8;
+    const int g = grid_for(n8);
+    const bf16x8* yy = (const bf16x8*)y;
+    const bf16x8* rr = (const bf16x8*)res;
+    bf16x8* oo = (bf16x8*)out;
+    if (res && relu)
+        hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+    else if (res)
+        hipLaunchKernelGGL((bn_apply_kernel<true, false>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+    else if (relu)
+        hipLaunchKernelGGL((bn_apply_kernel<false, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<false, false>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+    return VC_CHECK_LAUNCH();
+}
+
+static void reduce_geometry(long rows, int C, int& grid, int& rpb) {
+    const int rl = 256 / (C / 8);
+    long want = (rows + (long)rl * 8 - 1) / ((long)rl * 8);  // >= 8 rows per thread
+    if (want > 2048) want = 2048;
+    if (want < 1) want = 1;
+    rpb = (int)((rows + want - 1) / want);
+    grid = (int)((rows + rpb - 1) / rpb);
+}
+
+int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, hipStream_t s) {
+    int grid, rpb;
+    reduce_geometry(rows, C, grid, rpb);
+    hipLaunchKernelGGL((chan_reduce_kernel<0, 0>), dim3(grid), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)nullptr,
+                       (const bf16x8*)nullptr, (const float*)nullptr, sums, rows, C, rpb);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums, long rows,
+                        int C, int mask, hipStream_t s) {
+    int grid, rpb;
+    reduce_geometry(rows, C, grid, rpb);
+    const bf16x8 *yy = (const bf16x8*)y, *dd = (const bf16x8*)dz, *aa = (const bf16x8*)aux;
+    if (mask == 0)
+        hipLaunchKernelGGL((chan_reduce_kernel<1, 0>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
+    else if (mask == 1)
+        hipLaunchKernelGGL((chan_reduce_kernel<1, 1>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
+    else
+        hipLaunchKernelGGL((chan_reduce_kernel<1, 2>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_bn_bwd_finalize(const float* sums, int C, float count, float* coef, float* dgamma, float* dbeta,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, count, coef, dgamma,
+                       dbeta);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_bn_bwd_apply(const void* y, const void* dz, const void* aux, const float* params, const float* coef, void* dy,
+                       void* gout, long n, int C, int mask, hipStream_t s) {
+    const long n8 = n / 8;
+    const int g = grid_for(n8);
+    const bf16x8 *yy = (const bf16x8*)y, *dd = (const bf16x8*)dz, *aa = (const bf16x8*)aux;
+    bf16x8 *oo = (bf16x8*)dy, *gg = (bf16x8*)gout;
+#define VC_BWD_APPLY(M, G) \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<M, G>), dim3(g), dim3(256), 0, s, yy, dd, aa, params, coef, oo, gg, n8, C)
+    if (gout) {
+        if (mask == 0) VC_BWD_APPLY(0, true);
+        else if (mask == 1) VC_BWD_APPLY(1, true);
+        else VC_BWD_APPLY(2, true);
+    } else {
+        if (mask == 0) VC_BWD_APPLY(0, false);
+        else if (mask == 1) VC_BWD_APPLY(1, false);
+        else VC_BWD_APPLY(2, false);
+    }
+#undef VC_BWD_APPLY
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_add(const void* a, const void* b, void* out, long n, hipStream_t s) {
+    const long n8 = n / 8;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n8)), dim3(256), 0, s, (const bf16x8*)a, (const bf16x8*)b, (bf16x8*)out,
+                       n8);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_maxpool_fwd(const void* y, const float* params, void* out, uint8_t* idx, const VcPoolGeom& g, hipStream_t s) {
+    const long total = (long)g.N * g.To * g.Ho * g.Wo * (g.C / 8);
+    if (params)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<true>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16x8*)y, params,
+                           (bf16x8*)out, idx, g);
+    else
+        hipLaunchKernelGGL((maxpool_fwd_kernel<false>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16x8*)y, params,
+                           (bf16x8*)out, idx, g);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_maxpool_bwd(const void* dout, const uint8_t* idx, void* din, const VcPoolGeom& g, hipStream_t s) {
+    const long total = (long)g.N * g.T * g.H * g.W * (g.C / 8);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const bf16x8*)dout, idx, (bf16x8*)din,
+                       g);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_avgpool_fwd(const void* in, float* out, int N, int S, int C, hipStream_t s) {
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, (const bf16*)in, out, N, S, C);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_avgpool_bwd(const float* dfeat, void* din, int N, int S, int C, hipStream_t s) {
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)N * S * C)), dim3(256), 0, s, dfeat, (bf16*)din, N, S, C);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_linear_fwd(const float* feat, const float* W, const float* bias, float* out, int N, int F, int K,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((N * K + 3) / 4), dim3(256), 0, s, feat, W, bias, out, N, F, K);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_linear_bwd(const float* dlog, const float* feat, const float* W, float* dfeat, float* dW, float* db, int N,
+                     int F, int K, hipStream_t s) {
+    if (dfeat)
+        hipLaunchKernelGGL(linear_bwd_data_kernel, dim3((N * F + 255) / 256), dim3(256), 0, s, dlog, W, dfeat, N, F, K);
+    if (dW)
+        hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3((K * F + 255) / 256), dim3(256), 0, s, dlog, feat, dW, db, N, F,
+                           K);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_stem_pack_input(const void* x, int x_is_bf16, void* xs, int N, int T, int H, int W, hipStream_t s) {
+    const long total = (long)N * (T + 6) * (H / 2 + 3) * (W / 2 + 3);
+    if (x_is_bf16)
+        hipLaunchKernelGGL((stem_pack_input_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)x,
+                           (bf16*)xs, N, T, H, W);
+    else
+        hipLaunchKernelGGL((stem_pack_input_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)x,
+                           (bf16*)xs, N, T, H, W);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_ncs_to_nsc(const void* in, int in_is_bf16, void* out, int N, int C, long S, hipStream_t s) {
+    const long total = (long)N * C * S;
+    if (in_is_bf16)
+        hipLaunchKernelGGL((ncs_to_nsc_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in, (bf16*)out,
+                           N, C, S);
+    else
+        hipLaunchKernelGGL((ncs_to_nsc_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)in,
+                           (bf16*)out, N, C, S);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_nsc_to_ncs(const void* in, void* out, int out_is_bf16, int N, int C, long S, hipStream_t s) {
+    const long total = (long)N * C * S;
+    if (out_is_bf16)
+        hipLaunchKernelGGL((nsc_to_ncs_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in, (bf16*)out,
+                           N, C, S);
+    else
+        hipLaunchKernelGGL((nsc_to_ncs_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in,
+                           (float*)out, N, C, S);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_pack_weight(const float* w, void* wf, void* wd, int Co, int taps, int Ci, hipStream_t s) {
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((long)Co * taps * Ci)), dim3(256), 0, s, w, (bf16*)wf, (bf16*)wd,
+                       Co, taps, Ci);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_stem_pack_weight(const float* w, void* ws, int Co, hipStream_t s) {
+    hipLaunchKernelGGL(stem_pack_weight_kernel, dim3((Co * 1344 + 255) / 256), dim3(256), 0, s, w, (bf16*)ws, Co);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_stem_unpack_wgrad(const float* dws, float* dw, int Co, hipStream_t s) {
+    hipLaunchKernelGGL(stem_unpack_wgrad_kernel, dim3((Co * 1344 + 255) / 256), dim3(256), 0, s, dws, dw, Co);
+    return VC_CHECK_LAUNCH();
+}

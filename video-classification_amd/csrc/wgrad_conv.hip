@@ -1,0 +1,266 @@
+// Conv3d weight gradient on bf16 MFMA (gfx950).
+//
+// GEMM view:  dW[co][(tap, ci)] = sum_m dY[m][co] * X[src(m, tap)][ci]
+// The reduction index is the output position m, which is the slow (row) index of both
+// operands in channels-last memory.  Both operand tiles are therefore kept row-major in
+// LDS exactly as they arrive from global memory ([m][channel]) and the MFMA fragments are
+// fetched with ds_read_b64_tr_b16, the gfx950 transposing LDS read: a 16-lane group reads
+// a 4(m) x 16(channel) block and every lane receives 4 consecutive m of one channel.
+// Two such reads form the 8-deep K fragment of v_mfma_f32_16x16x32_bf16.  The m -> k slot
+// assignment is the same permutation for both operands, so the sum is unchanged.
+//
+// Work split: blockIdx.x = group of NB 64-wide column blocks (each block = one tap x 64 ci),
+// blockIdx.y = BCO-wide co block, blockIdx.z = slice of m (split-K).  Partial sums are added
+// to the fp32 gradient with float atomics (the gradient buffer is zeroed by the caller).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int RSX = 160;  // bytes per LDS row of a 64-channel tile: 128 data + 32 pad
+
+template <int BCO, int NB>
+struct WgCfg {
+    static constexpr int RSY = BCO * 2 + 32;
+    static constexpr int NY = BCO / 32;  // 16-B dY loads per thread per chunk
+    static constexpr int NXL = NB * 2;   // 16-B X loads per thread per chunk
+    static constexpr int LDS_BYTES = 64 * RSY + NB * 64 * RSX;
+    static_assert((BCO / 64) * NB == 4, "4 waves per workgroup");
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* base) {
+    // base: this lane's block-row address for the first read; second read is 16 rows below
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, lo, 0, 1, 2, 3, 0, 1, 2, 3));
+}
+
+template <int BCO, int NB, int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
+    using Cfg = WgCfg<BCO, NB>;
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sY = smem;
+    char* sX = smem + 64 * Cfg::RSY;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int co0 = blockIdx.y * BCO;
+    const int mb = blockIdx.z * p.rows_per_split;
+    const int mend = min(p.M, mb + p.rows_per_split);
+    const int nchunks = (mend - mb + 63) >> 6;
+
+    const int cpt = (MODE == 0) ? (p.Cs >> 6) : 1;
+    const int nblk = (MODE == 0) ? p.ntaps * cpt : (p.Kw >> 6);
+
+    // per-block (uniform) gather description
+    int b_soff[NB], b_ot[NB], b_oh[NB], b_ow[NB], b_col[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int cb = blockIdx.x * NB + b;
+        b_ok[b] = cb < nblk;
+        if (MODE == 0) {
+            const int tap = b_ok[b] ? cb / cpt : 0;
+            const int ci0 = (cb - tap * cpt) * 64;
+            b_soff[b] = p.taps[tap].src_off + ci0;
+            b_ot[b] = p.taps[tap].ot;
+            b_oh[b] = p.taps[tap].oh;
+            b_ow[b] = p.taps[tap].ow;
+            b_col[b] = p.taps[tap].wk_off + ci0;
+        } else {
+            b_soff[b] = 0;
+            b_ot[b] = b_oh[b] = b_ow[b] = 0;
+            b_col[b] = cb * 64;
+        }
+    }
+
+    const int lrow = tid >> 2;  // 0..63: the m row this thread stages
+    const int lsub = tid & 3;
+
+    // stem: per-piece source offsets (depend on the K group only)
+    int st_soff[NB][2];
+    if (MODE == 1) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int g = (blockIdx.x * NB + b) * 8 + lsub + 4 * h;
+                const int j = g / 6;
+                const int within = (g - j * 6) * 8;
+                st_soff[b][h] = (((j >> 2) * p.Hs + (j & 3)) * p.Ws) * p.Cs + within;
+            }
+    }
+
+    bf16x8 yr[Cfg::NY];
+    bf16x8 xr[NB][2];
+
+    auto load_chunk = [&](int c) {
+        const int m = mb + c * 64 + lrow;
+        const bool rowok = m < mend;
+        int base = 0, s_t = 0, s_h = 0, s_w = 0;
+        if (rowok) {
+            unsigned t1 = vc_div((unsigned)m, p.dWa);
+            int aw = m - (int)t1 * p.Wa;
+            unsigned t2 = vc_div(t1, p.dHa);
+            int ah = (int)t1 - (int)t2 * p.Ha;
+            unsigned n = vc_div(t2, p.dTa);
+            int at = (int)t2 - (int)n * p.Ta;
+            s_t = at * p.st;
+            s_h = ah * p.sh;
+            s_w = aw * p.sw;
+            base = ((((int)n * p.Ts + s_t) * p.Hs + s_h) * p.Ws + s_w) * p.Cs;
+        }
+#pragma unroll
+        for (int h = 0; h < Cfg::NY; ++h) {
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (rowok) v = *(const bf16x8*)(p.dy + ((size_t)m * p.Co + co0 + (lsub + 4 * h) * 8));
+            yr[h] = v;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            bool ok = rowok && b_ok[b];
+            if (MODE == 0) {
+                const int tt = s_t + b_ot[b], hh = s_h + b_oh[b], ww = s_w + b_ow[b];
+                ok = ok && (unsigned)tt < (unsigned)p.Ts && (unsigned)hh < (unsigned)p.Hs &&
+                     (unsigned)ww < (unsigned)p.Ws;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) {
+                    if (MODE == 0) {
+                        v = *(const bf16x8*)(p.x + (base + b_soff[b] + (lsub + 4 * h) * 8));
+                    } else {
+                        const bf16x4* q = (const bf16x4*)(p.x + (base + st_soff[b][h]));
+                        bf16x4 lo = q[0], hi = q[1];
+                        v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+                xr[b][h] = v;
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int h = 0; h < Cfg::NY; ++h) *(bf16x8*)(sY + lrow * Cfg::RSY + (lsub + 4 * h) * 16) = yr[h];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) *(bf16x8*)(sX + (b * 64 + lrow) * RSX + (lsub + 4 * h) * 16) = xr[b][h];
+    };
+
+    // wave roles
+    const int wco = (BCO == 128) ? (wave & 1) : 0;
+    const int wb = (BCO == 128) ? (wave >> 1) : wave;
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+    const int q = l15 >> 2, pp = l15 & 3;
+    // address of this lane's row/column inside a 4x16 transposed-read block
+    const char* aY = sY + (4 * lg + q) * Cfg::RSY + (wco * 64 + 4 * pp) * 2;
+    const char* aX = sX + (wb * 64 + 4 * lg + q) * RSX + (4 * pp) * 2;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk();
+    }
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = (c + 1 < nchunks);
+        if (more) load_chunk(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const char* r0 = aY + (ks * 32) * Cfg::RSY + a * 32;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(r0));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(r0 + 16 * Cfg::RSY));
+                fa[a] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const char* r0 = aX + (ks * 32) * RSX + b * 32;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(r0));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(r0 + 16 * RSX));
+                fb[b] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: acc[a][b][j] = dW[co0 + wco*64 + a*16 + lg*4 + j][col(wb) + b*16 + l15]
+    if (nchunks <= 0) return;
+    bool okb = false;
+    int colb = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b == wb) {
+            okb = b_ok[b];
+            colb = b_col[b];
+        }
+    if (!okb) return;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* row = p.dw + (size_t)(co0 + wco * 64 + a * 16 + lg * 4 + j) * p.Kw + colb + l15;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) atomicAdd(row + b * 16, acc[a][b][j]);
+        }
+}
+
+template <int BCO, int NB, int MODE>
+int launch_wgrad(const VcWgradParams& p, int splits, hipStream_t stream) {
+    using Cfg = WgCfg<BCO, NB>;
+    const int nblk = (MODE == 0) ? p.ntaps * (p.Cs / 64) : p.Kw / 64;
+    dim3 grid((nblk + NB - 1) / NB, p.Co / BCO, splits);
+    hipLaunchKernelGGL((wgrad_kernel<BCO, NB, MODE>), grid, dim3(256), Cfg::LDS_BYTES, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+int vc_launch_wgrad(const VcWgradParams& p_in, int mode, hipStream_t stream) {
+    VcWgradParams p = p_in;
+    if (p.M <= 0) return 0;
+    if (p.Co % 64 != 0 || (mode == 0 && p.Cs % 64 != 0) || p.Kw % 64 != 0) {
+        vc_set_error("wgrad: channels must be multiples of 64 (Co=%d Cs=%d Kw=%d)", p.Co, p.Cs, p.Kw);
+        return -2;
+    }
+    const bool wide = (p.Co % 128 == 0);
+    const int nb = wide ? 2 : 4;
+    const int bco = wide ? 128 : 64;
+    const int nblk = (mode == 0) ? p.ntaps * (p.Cs / 64) : p.Kw / 64;
+    const long tiles = (long)((nblk + nb - 1) / nb) * (p.Co / bco);
+    // aim for ~1024 workgroups, at least 4 chunks (256 rows) per split
+    long splits = (1024 + tiles - 1) / tiles;
+    const long maxsplits = (p.M + 255) / 256;
+    if (splits > maxsplits) splits = maxsplits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    long rps = (p.M + splits - 1) / splits;
+    rps = (rps + 63) / 64 * 64;
+    splits = (p.M + rps - 1) / rps;
+    p.rows_per_split = (int)rps;
+    if (mode == 1) return launch_wgrad<64, 4, 1>(p, (int)splits, stream);
+    if (wide) return launch_wgrad<128, 2, 0>(p, (int)splits, stream);
+    return launch_wgrad<64, 4, 0>(p, (int)splits, stream);
+}

@@ -1,0 +1,321 @@
+"""Tensor-level wrappers over the C ABI (include/vc3d.h).
+
+Every wrapper checks device, dtype, contiguity and element counts on the host before the
+launch: a kernel that reads past a buffer can take the whole GPU down.  torch is used for
+device memory and the current stream only.
+"""
+import torch
+
+from . import capi
+from .capi import ConvDesc, PoolDesc, VC_STAT_REPLICAS, STEM_K, check, lib, ptr, cur_stream
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _chk(t, dtype, numel=None, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise capi.Vc3dError("%s must be a CUDA/HIP tensor: the vc3d path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise capi.Vc3dError("%s: expected %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise capi.Vc3dError("%s must be contiguous" % name)
+    if numel is not None and t.numel() != numel:
+        raise capi.Vc3dError("%s: expected %d elements, got %d" % (name, numel, t.numel()))
+
+
+def conv_desc(N, Ci, T, H, W, Co, k, s, p):
+    k = (k,) * 3 if isinstance(k, int) else tuple(k)
+    s = (s,) * 3 if isinstance(s, int) else tuple(s)
+    p = (p,) * 3 if isinstance(p, int) else tuple(p)
+    return ConvDesc(N, Ci, T, H, W, Co, *k, *s, *p)
+
+
+def new_stats(C, device):
+    return torch.zeros(VC_STAT_REPLICAS, 2, C, dtype=F32, device=device)
+
+
+# ------------------------------------------------------------------ conv
+def pack_weight(w_master, want_dgrad=True):
+    """w_master: fp32 parameter [Co][Ci][kt][kh][kw] stored channels_last_3d."""
+    Co, Ci, kt, kh, kw = w_master.shape
+    wm = w_master.detach().permute(0, 2, 3, 4, 1)  # physical [Co][kt][kh][kw][Ci]
+    _chk(wm, F32, name="w_master (channels_last_3d)")
+    taps = kt * kh * kw
+    wf = torch.empty(Co, taps * Ci, dtype=BF16, device=wm.device)
+    wd = torch.empty(Ci, taps * Co, dtype=BF16, device=wm.device) if want_dgrad else None
+    check(lib.vc_pack_weight(ptr(wm), ptr(wf), ptr(wd), Co, taps, Ci, cur_stream()), "vc_pack_weight")
+    return wf, wd
+
+
+def conv3d_fwd(d, x, wf, stats=None, out=None):
+    To, Ho, Wo = d.out_dims()
+    taps = d.kt * d.kh * d.kw
+    _chk(x, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "x")
+    _chk(wf, BF16, d.Co * taps * d.Ci, "w")
+    if out is None:
+        out = torch.empty(d.N, To, Ho, Wo, d.Co, dtype=BF16, device=x.device)
+    _chk(out, BF16, d.N * To * Ho * Wo * d.Co, "y")
+    _chk(stats, F32, VC_STAT_REPLICAS * 2 * d.Co, "bn_stats")
+    check(lib.vc_conv3d_fwd(d, ptr(x), ptr(wf), ptr(out), ptr(stats), cur_stream()), "vc_conv3d_fwd")
+    return out
+
+
+def conv3d_dgrad(d, dy, wd, out=None, accumulate=False):
+    To, Ho, Wo = d.out_dims()
+    taps = d.kt * d.kh * d.kw
+    _chk(dy, BF16, d.N * To * Ho * Wo * d.Co, "dy")
+    _chk(wd, BF16, d.Ci * taps * d.Co, "w_dgrad")
+    if out is None:
+        if accumulate:
+            raise capi.Vc3dError("conv3d_dgrad: accumulate needs an existing dx")
+        out = torch.empty(d.N, d.Ti, d.Hi, d.Wi, d.Ci, dtype=BF16, device=dy.device)
+    _chk(out, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "dx")
+    check(lib.vc_conv3d_dgrad(d, ptr(dy), ptr(wd), ptr(out), 1 if accumulate else 0, cur_stream()), "vc_conv3d_dgrad")
+    return out
+
+
+def conv3d_wgrad(d, x, dy, dw):
+    """dw: fp32 [Co][kt][kh][kw][Ci] (physical), accumulated into."""
+    To, Ho, Wo = d.out_dims()
+    taps = d.kt * d.kh * d.kw
+    _chk(x, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "x")
+    _chk(dy, BF16, d.N * To * Ho * Wo * d.Co, "dy")
+    _chk(dw, F32, d.Co * taps * d.Ci, "dw")
+    check(lib.vc_conv3d_wgrad(d, ptr(x), ptr(dy), ptr(dw), cur_stream()), "vc_conv3d_wgrad")
+    return dw
+
+
+# ------------------------------------------------------------------ stem
+def stem_pack_input(x):
+    """x: [N][3][T][H][W] fp32 or bf16 (contiguous) -> padded space-to-depth bf16 source."""
+    N, Cc, T, H, W = x.shape
+    if Cc != 3:
+        raise capi.Vc3dError("stem expects 3 input channels, got %d" % Cc)
+    if x.dtype not in (F32, BF16):
+        raise capi.Vc3dError("stem input must be fp32 or bf16")
+    _chk(x, x.dtype, name="clip")
+    xs = torch.empty(N, T + 6, H // 2 + 3, W // 2 + 3, 12, dtype=BF16, device=x.device)
+    check(lib.vc_stem_pack_input(ptr(x), 1 if x.dtype == BF16 else 0, ptr(xs), N, T, H, W, cur_stream()),
+          "vc_stem_pack_input")
+    return xs
+
+
+def stem_pack_weight(w_master):
+    Co = w_master.shape[0]
+    if tuple(w_master.shape[1:]) != (3, 7, 7, 7):
+        raise capi.Vc3dError("stem weight must be [Co][3][7][7][7]")
+    wm = w_master.detach().permute(0, 2, 3, 4, 1)
+    _chk(wm, F32, name="stem w_master (channels_last_3d)")
+    ws = torch.empty(Co, STEM_K, dtype=BF16, device=wm.device)
+    check(lib.vc_stem_pack_weight(ptr(wm), ptr(ws), Co, cur_stream()), "vc_stem_pack_weight")
+    return ws
+
+
+def stem_fwd(xs, ws, N, T, H, W, Co, stats=None, out=None):
+    _chk(xs, BF16, N * (T + 6) * (H // 2 + 3) * (W // 2 + 3) * 12, "xs")
+    _chk(ws, BF16, Co * STEM_K, "ws")
+    if out is None:
+        out = torch.empty(N, T, H // 2, W // 2, Co, dtype=BF16, device=xs.device)
+    _chk(out, BF16, N * T * (H // 2) * (W // 2) * Co, "y")
+    _chk(stats, F32, VC_STAT_REPLICAS * 2 * Co, "bn_stats")
+    check(lib.vc_stem_fwd(ptr(xs), ptr(ws), ptr(out), ptr(stats), N, T, H, W, Co, cur_stream()), "vc_stem_fwd")
+    return out
+
+
+def stem_wgrad(xs, dy, N, T, H, W, Co, dw_master_phys, scratch=None):
+    """dw_master_phys: fp32 [Co][7][7][7][3] physical view of the stem gradient, accumulated into."""
+    _chk(xs, BF16, N * (T + 6) * (H // 2 + 3) * (W // 2 + 3) * 12, "xs")
+    _chk(dy, BF16, N * T * (H // 2) * (W // 2) * Co, "dy")
+    _chk(dw_master_phys, F32, Co * 1029, "dw")
+    if scratch is None:
+        scratch = torch.zeros(Co, STEM_K, dtype=F32, device=xs.device)
+    else:
+        _chk(scratch, F32, Co * STEM_K, "stem wgrad scratch")
+        scratch.zero_()
+    check(lib.vc_stem_wgrad(ptr(xs), ptr(dy), ptr(scratch), N, T, H, W, Co, cur_stream()), "vc_stem_wgrad")
+    check(lib.vc_stem_unpack_wgrad(ptr(scratch), ptr(dw_master_phys), Co, cur_stream()), "vc_stem_unpack_wgrad")
+    return dw_master_phys
+
+
+# ------------------------------------------------------------------ batch norm
+def bn_stats(y, C, sums=None):
+    _chk(y, BF16, name="y")
+    rows = y.numel() // C
+    if sums is None:
+        sums = new_stats(C, y.device)
+    _chk(sums, F32, VC_STAT_REPLICAS * 2 * C, "sums")
+    check(lib.vc_bn_stats(ptr(y), ptr(sums), rows, C, cur_stream()), "vc_bn_stats")
+    return sums
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, params=None):
+    Cn = gamma.numel()
+    _chk(stats, F32, VC_STAT_REPLICAS * 2 * Cn, "stats")
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _chk(t, F32, Cn, nm)
+    if params is None:
+        params = torch.empty(4, Cn, dtype=F32, device=gamma.device)
+    _chk(params, F32, 4 * Cn, "bn params")
+    check(lib.vc_bn_finalize(ptr(stats), Cn, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
+                             ptr(running_var), float(momentum), float(eps), ptr(params), cur_stream()),
+          "vc_bn_finalize")
+    return params
+
+
+def bn_eval_params(gamma, beta, running_mean, running_var, eps, params=None):
+    Cn = gamma.numel()
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _chk(t, F32, Cn, nm)
+    if params is None:
+        params = torch.empty(4, Cn, dtype=F32, device=gamma.device)
+    _chk(params, F32, 4 * Cn, "bn params")
+    check(lib.vc_bn_eval_params(Cn, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps),
+                                ptr(params), cur_stream()), "vc_bn_eval_params")
+    return params
+
+
+def bn_apply(y, params, C, residual=None, relu=True, out=None):
+    _chk(y, BF16, name="y")
+    _chk(params, F32, 4 * C, "bn params")
+    _chk(residual, BF16, y.numel(), "residual")
+    if out is None:
+        out = torch.empty_like(y)
+    _chk(out, BF16, y.numel(), "out")
+    check(lib.vc_bn_apply(ptr(y), ptr(params), ptr(residual), ptr(out), y.numel(), C, 1 if relu else 0,
+                          cur_stream()), "vc_bn_apply")
+    return out
+
+
+def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=False, sums=None, coef=None,
+           dy=None, g_out=None):
+    """BatchNorm backward (batch statistics).  Returns (dy, g) with g = masked dz or None."""
+    n = y.numel()
+    _chk(y, BF16, name="y")
+    _chk(dz, BF16, n, "dz")
+    _chk(aux, BF16, n, "aux")
+    _chk(params, F32, 4 * C, "bn params")
+    _chk(gamma_grad, F32, C, "dgamma")
+    _chk(beta_grad, F32, C, "dbeta")
+    rows = n // C
+    if sums is None:
+        sums = new_stats(C, y.device)
+    _chk(sums, F32, VC_STAT_REPLICAS * 2 * C, "sums")
+    if coef is None:
+        coef = torch.empty(2, C, dtype=F32, device=y.device)
+    _chk(coef, F32, 2 * C, "coef")
+    if dy is None:
+        dy = torch.empty_like(y)
+    _chk(dy, BF16, n, "dy")
+    if want_g and g_out is None:
+        g_out = torch.empty_like(y)
+    _chk(g_out, BF16, n, "g_out")
+    s = cur_stream()
+    check(lib.vc_bn_bwd_reduce(ptr(y), ptr(dz), ptr(aux), ptr(params), ptr(sums), rows, C, mask, s),
+          "vc_bn_bwd_reduce")
+    check(lib.vc_bn_bwd_finalize(ptr(sums), C, float(rows), ptr(coef), ptr(gamma_grad), ptr(beta_grad), s),
+          "vc_bn_bwd_finalize")
+    check(lib.vc_bn_bwd_apply(ptr(y), ptr(dz), ptr(aux), ptr(params), ptr(coef), ptr(dy), ptr(g_out), n, C, mask, s),
+          "vc_bn_bwd_apply")
+    return dy, g_out
+
+
+def add(a, b, out=None):
+    _chk(a, BF16, name="a")
+    _chk(b, BF16, a.numel(), "b")
+    if out is None:
+        out = torch.empty_like(a)
+    _chk(out, BF16, a.numel(), "out")
+    check(lib.vc_add(ptr(a), ptr(b), ptr(out), a.numel(), cur_stream()), "vc_add")
+    return out
+
+
+# ------------------------------------------------------------------ pooling / head / layout
+def pool_desc(N, C, T, H, W, k=3, s=2, p=1):
+    k = (k,) * 3 if isinstance(k, int) else tuple(k)
+    s = (s,) * 3 if isinstance(s, int) else tuple(s)
+    p = (p,) * 3 if isinstance(p, int) else tuple(p)
+    return PoolDesc(N, C, T, H, W, *k, *s, *p)
+
+
+def maxpool3d_fwd(d, y, bn_params=None):
+    To, Ho, Wo = d.out_dims()
+    _chk(y, BF16, d.N * d.T * d.H * d.W * d.C, "y")
+    _chk(bn_params, F32, 4 * d.C, "bn params")
+    out = torch.empty(d.N, To, Ho, Wo, d.C, dtype=BF16, device=y.device)
+    idx = torch.empty(d.N, To, Ho, Wo, d.C, dtype=torch.uint8, device=y.device)
+    check(lib.vc_maxpool3d_fwd(d, ptr(y), ptr(bn_params), ptr(out), ptr(idx), cur_stream()), "vc_maxpool3d_fwd")
+    return out, idx
+
+
+def maxpool3d_bwd(d, dout, idx):
+    To, Ho, Wo = d.out_dims()
+    _chk(dout, BF16, d.N * To * Ho * Wo * d.C, "dout")
+    _chk(idx, torch.uint8, d.N * To * Ho * Wo * d.C, "argmax")
+    din = torch.empty(d.N, d.T, d.H, d.W, d.C, dtype=BF16, device=dout.device)
+    check(lib.vc_maxpool3d_bwd(d, ptr(dout), ptr(idx), ptr(din), cur_stream()), "vc_maxpool3d_bwd")
+    return din
+
+
+def gavgpool_fwd(x, N, S, Cn):
+    _chk(x, BF16, N * S * Cn, "x")
+    out = torch.empty(N, Cn, dtype=F32, device=x.device)
+    check(lib.vc_gavgpool_fwd(ptr(x), ptr(out), N, S, Cn, cur_stream()), "vc_gavgpool_fwd")
+    return out
+
+
+def gavgpool_bwd(dfeat, N, S, Cn, shape):
+    _chk(dfeat, F32, N * Cn, "dfeat")
+    din = torch.empty(shape, dtype=BF16, device=dfeat.device)
+    _chk(din, BF16, N * S * Cn, "din")
+    check(lib.vc_gavgpool_bwd(ptr(dfeat), ptr(din), N, S, Cn, cur_stream()), "vc_gavgpool_bwd")
+    return din
+
+
+def linear_fwd(feat, W, bias):
+    N, Fd = feat.shape
+    K = W.shape[0]
+    _chk(feat, F32, name="feat")
+    _chk(W, F32, K * Fd, "W")
+    _chk(bias, F32, K, "bias")
+    out = torch.empty(N, K, dtype=F32, device=feat.device)
+    check(lib.vc_linear_fwd(ptr(feat), ptr(W), ptr(bias), ptr(out), N, Fd, K, cur_stream()), "vc_linear_fwd")
+    return out
+
+
+def linear_bwd(dlogits, feat, W, dW=None, db=None, want_dfeat=True):
+    N, K = dlogits.shape
+    Fd = W.shape[1]
+    _chk(dlogits, F32, name="dlogits")
+    _chk(feat, F32, N * Fd, "feat")
+    _chk(W, F32, K * Fd, "W")
+    _chk(dW, F32, K * Fd, "dW")
+    _chk(db, F32, K, "db")
+    dfeat = torch.empty(N, Fd, dtype=F32, device=dlogits.device) if want_dfeat else None
+    check(lib.vc_linear_bwd(ptr(dlogits), ptr(feat), ptr(W), ptr(dfeat), ptr(dW), ptr(db), N, Fd, K, cur_stream()),
+          "vc_linear_bwd")
+    return dfeat
+
+
+def ncthw_to_nthwc(x):
+    N, Cc = x.shape[0], x.shape[1]
+    S = x.numel() // (N * Cc)
+    if x.dtype not in (F32, BF16):
+        raise capi.Vc3dError("layout: fp32 or bf16 only")
+    _chk(x, x.dtype, name="x")
+    out = torch.empty((N,) + tuple(x.shape[2:]) + (Cc,), dtype=BF16, device=x.device)
+    check(lib.vc_ncthw_to_nthwc(ptr(x), 1 if x.dtype == BF16 else 0, ptr(out), N, Cc, S, cur_stream()),
+          "vc_ncthw_to_nthwc")
+    return out
+
+
+def nthwc_to_ncthw(x, dtype=F32):
+    N, Cc = x.shape[0], x.shape[-1]
+    S = x.numel() // (N * Cc)
+    _chk(x, BF16, name="x")
+    out = torch.empty((N, Cc) + tuple(x.shape[1:-1]), dtype=dtype, device=x.device)
+    check(lib.vc_nthwc_to_ncthw(ptr(x), ptr(out), 1 if dtype == BF16 else 0, N, Cc, S, cur_stream()),
+          "vc_nthwc_to_ncthw")
+    return out
