@@ -1,0 +1,62 @@
+"""Host-side helpers with the reference's names (/root/reference/lib/utils/utils.py)."""
+import logging
+import os
+import time
+
+import torch
+
+
+def create_optimizer(cfg, model):
+    """SGD(momentum, wd, nesterov) or Adam(lr); None for any other name (reference utils.py:13-36)."""
+    name = cfg.TRAIN.OPTIMIZER
+    params = [p for p in model.parameters()]
+    if name == 'sgd':
+        return torch.optim.SGD(params, lr=cfg.TRAIN.LR, momentum=cfg.TRAIN.MOMENTUM,
+                               weight_decay=cfg.TRAIN.WD, nesterov=cfg.TRAIN.NESTEROV)
+    if name == 'adam':
+        return torch.optim.Adam(params, lr=cfg.TRAIN.LR)
+    return None
+
+
+class AverageMeter(object):
+    """running value / sum / count / average (reference utils.py:39-54)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count if self.count else 0
+
+
+def ChooseInput(vedio, action):
+    """reference utils.py:57-64 is an empty stub (frame/modality picking of the unfinished RL
+    design).  Here the whole clip is the model input whatever the action."""
+    return vedio
+
+
+def rollout(vedio, model, action, value):
+    """reference utils.py:67-80 is an empty stub.  Returns (log_prob, advantages) = (None, None):
+    no actor/critic terms, so Loss reduces to cross-entropy."""
+    return None, None
+
+
+def create_logger(cfg, phase='train'):
+    """file + console logger; file name {DATASET}_{time}_{phase}.log under OUTPUT_DIR
+    (reference utils.py:84-104)."""
+    os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)
+    stamp = time.strftime('%Y-%m-%d-%H-%M')
+    path = os.path.join(cfg.OUTPUT_DIR, '{}_{}_{}.log'.format(cfg.DATASET, stamp, phase))
+    logger = logging.getLogger()
+    logger.setLevel(logging.INFO)
+    fmt = logging.Formatter('%(asctime)-15s: %(message)s')
+    fh = logging.FileHandler(path)
+    fh.setFormatter(fmt)
+    logger.addHandler(fh)
+    logger.addHandler(logging.StreamHandler())
+    return logger

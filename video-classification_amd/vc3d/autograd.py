@@ -1,0 +1,72 @@
+"""The two autograd nodes of the product path: the whole backbone, and the classifier head.
+
+The backbone node owns its backward (engine.backward) and writes parameter gradients
+straight into the engine's flat gradient buffer, assigning ``param.grad`` itself; it returns
+None for the parameter inputs, so ``torch.autograd.grad`` on backbone parameters is not
+supported (``loss.backward()`` + optimizer, the reference's loop, is).
+"""
+import torch
+
+from . import ops
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, engine, training, anchor, *params):
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        feat, saved = engine.forward(x, training, save=need_grad)
+        ctx.engine = engine
+        ctx.saved = saved
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        eng = ctx.engine
+        if ctx.saved is None:
+            raise RuntimeError("backbone forward ran without saving activations")
+        eng._bind_grads()
+        eng.backward(ctx.saved, dfeat)
+        ctx.saved = None
+        return (None, None, None, None) + (None,) * len(eng._fn_params)
+
+
+def backbone_apply(engine, x, training):
+    params = engine.params_backward_order()
+    engine._fn_params = params
+    if engine.flat_grad is None or engine.flat_grad.device != params[0].device:
+        engine.setup_grads(extra_first=getattr(engine, "head_params", ()))
+    return _BackboneFn.apply(x, engine, training, None, *params)
+
+
+class _LinearFn(torch.autograd.Function):
+    """classifier head; when ``engine`` is given, W/b gradients go to its flat buffer."""
+
+    @staticmethod
+    def forward(ctx, feat, W, b, engine):
+        ctx.save_for_backward(feat, W)
+        ctx.has_bias = b is not None
+        ctx.engine = engine
+        ctx.params = (W, b)
+        return ops.linear_fwd(feat.contiguous(), W.detach(), None if b is None else b.detach())
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        feat, W = ctx.saved_tensors
+        Wp, bp = ctx.params
+        eng = ctx.engine
+        if eng is not None and eng.flat_grad is not None and id(Wp) in eng.grad_views:
+            eng._bind_grads()
+            dW = eng.gview(Wp)
+            db = eng.gview(bp) if bp is not None else None
+            dfeat = ops.linear_bwd(dlogits.contiguous(), feat, W.detach(), dW, db,
+                                   want_dfeat=ctx.needs_input_grad[0])
+            eng._ready(Wp, *( [bp] if bp is not None else []))
+            return dfeat, None, None, None
+        dW = torch.zeros_like(W)
+        db = torch.zeros(W.shape[0], dtype=W.dtype, device=W.device) if ctx.has_bias else None
+        dfeat = ops.linear_bwd(dlogits.contiguous(), feat, W.detach(), dW, db, want_dfeat=ctx.needs_input_grad[0])
+        return dfeat, dW, db, None
+
+
+def linear_apply(feat, W, b, engine=None):
+    return _LinearFn.apply(feat, W, b, engine)

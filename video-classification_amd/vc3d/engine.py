@@ -1,0 +1,325 @@
+"""Forward/backward executor of the 3D-ResNet backbone on the vc3d HIP kernels.
+
+The nn.Module tree (lib/models/backbone.py) only holds parameters and buffers under the
+reference's names.  This executor walks that tree and issues the kernel sequence itself --
+forward, and a hand-written backward in reverse order -- instead of recording one autograd
+node per op.  That keeps every activation in channels-last bf16, lets the BatchNorm
+statistics ride in the conv epilogue, and tells the data-parallel layer exactly when each
+gradient is final so its bucket can be all-reduced while the rest of backward runs.
+
+Gradients are written into one flat fp32 buffer (reverse layer order); ``param.grad`` are
+views of it with the parameter's own strides.
+"""
+import torch
+
+from . import ops
+from .capi import VC_STAT_REPLICAS, Vc3dError
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _triple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+class _ConvBN:
+    """one conv + its BatchNorm: geometry cache, packed weights, saved tensors."""
+
+    def __init__(self, conv, bn, name):
+        self.conv, self.bn, self.name = conv, bn, name
+        self.k, self.s, self.p = _triple(conv.kernel_size), _triple(conv.stride), _triple(conv.padding)
+        self.Ci, self.Co = conv.in_channels, conv.out_channels
+        self.wf = self.wd = None
+        self.wver = -1
+        self.eval_params = None
+        self.eval_ver = None
+
+    def desc(self, x):
+        N, T, H, W, C = x.shape
+        if C != self.Ci:
+            raise Vc3dError("%s: expected %d input channels, got %d" % (self.name, self.Ci, C))
+        return ops.conv_desc(N, C, T, H, W, self.Co, self.k, self.s, self.p)
+
+    def weights(self):
+        w = self.conv.weight
+        if self.wver != w._version or self.wf is None or self.wf.device != w.device:
+            self.wf, self.wd = ops.pack_weight(w, want_dgrad=True)
+            self.wver = w._version
+        return self.wf, self.wd
+
+
+class R3DEngine:
+    def __init__(self, backbone):
+        self.bb = backbone
+        self.stem = _ConvBN(backbone.conv1, backbone.bn1, "conv1")
+        if (self.stem.k, self.stem.s, self.stem.p, self.stem.Ci) != ((7, 7, 7), (1, 2, 2), (3, 3, 3), 3):
+            raise Vc3dError("stem must be 7x7x7 stride (1,2,2) pad 3 on 3 channels")
+        self.stem_ws = None
+        self.stem_wver = -1
+        self.pool = (_triple(backbone.maxpool.kernel_size), _triple(backbone.maxpool.stride),
+                     _triple(backbone.maxpool.padding))
+        self.blocks = []
+        for li in range(1, 5):
+            layer = getattr(backbone, "layer%d" % li)
+            for bi, blk in enumerate(layer):
+                pre = "layer%d.%d" % (li, bi)
+                cbs = [_ConvBN(blk.conv1, blk.bn1, pre + ".conv1"), _ConvBN(blk.conv2, blk.bn2, pre + ".conv2")]
+                if hasattr(blk, "conv3"):
+                    cbs.append(_ConvBN(blk.conv3, blk.bn3, pre + ".conv3"))
+                ds = None
+                if blk.downsample is not None:
+                    ds = _ConvBN(blk.downsample[0], blk.downsample[1], pre + ".downsample")
+                self.blocks.append((cbs, ds))
+        self.flat_grad = None
+        self.grad_views = None
+        self.grad_ready_cb = None  # set by the data-parallel wrapper: cb(param)
+        self._stem_scratch = None
+
+    # ------------------------------------------------------------------ parameters
+    def all_convbn(self):
+        yield self.stem
+        for cbs, ds in self.blocks:
+            for cb in cbs:
+                yield cb
+            if ds is not None:
+                yield ds
+
+    def params_backward_order(self):
+        """parameters in the order their gradients become final during backward."""
+        out = []
+        for cbs, ds in reversed(self.blocks):
+            seq = list(reversed(cbs))
+            # block backward: last bn/conv first, downsample, then first conv
+            for cb in seq[:-1]:
+                out += [cb.bn.weight, cb.bn.bias, cb.conv.weight]
+            if ds is not None:
+                out += [ds.bn.weight, ds.bn.bias, ds.conv.weight]
+            out += [seq[-1].bn.weight, seq[-1].bn.bias, seq[-1].conv.weight]
+        out += [self.stem.bn.weight, self.stem.bn.bias, self.stem.conv.weight]
+        return out
+
+    def setup_grads(self, extra_first=()):
+        """(re)create the flat gradient buffer; ``extra_first`` are parameters (the head's) whose
+        gradients come before the backbone's."""
+        plist = list(extra_first) + self.params_backward_order()
+        dev = plist[0].device
+        total = sum(p.numel() for p in plist)
+        self.flat_grad = torch.zeros(total, dtype=F32, device=dev)
+        self.grad_views = {}
+        self.grad_ranges = []
+        off = 0
+        for p in plist:
+            n = p.numel()
+            seg = self.flat_grad[off:off + n]
+            if p.dim() == 5:
+                Co, Ci, kt, kh, kw = p.shape
+                v = seg.view(Co, kt, kh, kw, Ci).permute(0, 4, 1, 2, 3)
+                if v.stride() != p.stride() and p.numel() > 1:
+                    # parameter is not channels_last_3d (e.g. freshly loaded): convert it in place
+                    with torch.no_grad():
+                        p.data = p.data.contiguous(memory_format=torch.channels_last_3d)
+            else:
+                v = seg.view(p.shape)
+            self.grad_views[id(p)] = v
+            self.grad_ranges.append((p, off, n))
+            off += n
+        self.plist = plist
+        return self.flat_grad
+
+    def _bind_grads(self):
+        """point every param.grad at its flat view (keeping accumulated values)."""
+        if self.flat_grad is None or self.flat_grad.device != self.plist[0].device:
+            raise Vc3dError("engine.setup_grads() has not been called for this device")
+        fresh = True
+        for p in self.plist:
+            v = self.grad_views[id(p)]
+            if p.grad is None:
+                continue
+            if p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == v.stride():
+                fresh = False
+        if fresh:
+            self.flat_grad.zero_()
+        for p in self.plist:
+            v = self.grad_views[id(p)]
+            if p.grad is None:
+                if not fresh:
+                    v.zero_()
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+                p.grad = v
+
+    def gview(self, p):
+        return self.grad_views[id(p)]
+
+    def _gphys(self, p):
+        """physical [Co][kt][kh][kw][Ci] contiguous view of a conv weight gradient."""
+        return self.grad_views[id(p)].permute(0, 2, 3, 4, 1)
+
+    def _ready(self, *params):
+        if self.grad_ready_cb is not None:
+            for p in params:
+                self.grad_ready_cb(p)
+
+    # ------------------------------------------------------------------ forward
+    def _bn_params(self, cb, stats, count, training):
+        bn = cb.bn
+        if training:
+            if bn.momentum is None:
+                raise Vc3dError("cumulative-average BatchNorm (momentum=None) is not supported")
+            p = ops.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(),
+                                bn.running_mean if bn.track_running_stats else None,
+                                bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps)
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            return p
+        ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version)
+        if cb.eval_params is None or cb.eval_ver != ver or cb.eval_params.device != bn.weight.device:
+            cb.eval_params = ops.bn_eval_params(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                                bn.running_var, bn.eps)
+            cb.eval_ver = ver
+        return cb.eval_params
+
+    def _conv_bn(self, cb, x, training, stats_pool):
+        d = cb.desc(x)
+        wf, _ = cb.weights()
+        stats = stats_pool.take(cb.Co) if training else None
+        y = ops.conv3d_fwd(d, x, wf, stats=stats)
+        count = y.numel() // cb.Co
+        params = self._bn_params(cb, stats, count, training)
+        return d, y, params
+
+    def forward(self, x, training, save):
+        """x: [N][3][T][H][W] fp32/bf16 on the GPU.  Returns (features fp32 [N][F], saved state)."""
+        if x.dim() != 5 or x.shape[1] != 3:
+            raise Vc3dError("expected a clip batch N x 3 x T x H x W, got %s" % (tuple(x.shape),))
+        if not x.is_cuda:
+            raise Vc3dError("the vc3d backbone runs on the GPU only (no CPU fallback); move the clips to cuda")
+        if x.dtype not in (F32, BF16):
+            x = x.float()
+        x = x.contiguous()
+        N, _, T, H, W = x.shape
+        dev = x.device
+        nbn = sum(1 for _ in self.all_convbn())
+        stats_pool = _StatsPool(sum(cb.Co for cb in self.all_convbn()), dev) if training else None
+        st = self.stem
+        w = st.conv.weight
+        if self.stem_wver != w._version or self.stem_ws is None or self.stem_ws.device != dev:
+            self.stem_ws = ops.stem_pack_weight(w)
+            self.stem_wver = w._version
+        xs = ops.stem_pack_input(x)
+        stats0 = stats_pool.take(st.Co) if training else None
+        y0 = ops.stem_fwd(xs, self.stem_ws, N, T, H, W, st.Co, stats=stats0)
+        p0 = self._bn_params(st, stats0, y0.numel() // st.Co, training)
+        pk, ps, pp = self.pool
+        pd = ops.pool_desc(N, st.Co, T, H // 2, W // 2, pk, ps, pp)
+        a0, idx = ops.maxpool3d_fwd(pd, y0, p0)
+        saved = {"stem": (xs, y0, p0, pd, idx, (N, T, H, W)), "blocks": []} if save else None
+        if not save:
+            del xs, y0, idx
+        cur = a0
+        for cbs, ds in self.blocks:
+            xin = cur
+            recs = []
+            h = xin
+            for i, cb in enumerate(cbs):
+                d, y, prm = self._conv_bn(cb, h, training, stats_pool)
+                last = (i == len(cbs) - 1)
+                if not last:
+                    z = ops.bn_apply(y, prm, cb.Co, relu=True)
+                    recs.append((d, h, y, prm, z))
+                    h = z
+                else:
+                    if ds is not None:
+                        dd, yd, prmd = self._conv_bn(ds, xin, training, stats_pool)
+                        r = ops.bn_apply(yd, prmd, ds.Co, relu=False)
+                    else:
+                        dd = yd = prmd = None
+                        r = xin
+                    out = ops.bn_apply(y, prm, cb.Co, residual=r, relu=True)
+                    recs.append((d, h, y, prm, out))
+                    dsrec = (dd, yd, prmd)
+            if save:
+                saved["blocks"].append((xin, recs, dsrec))
+            cur = out
+        Nn, To, Ho, Wo, Cf = cur.shape
+        feat = ops.gavgpool_fwd(cur, Nn, To * Ho * Wo, Cf)
+        if save:
+            saved["final"] = (tuple(cur.shape),)
+        return feat, saved
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, saved, dfeat):
+        """dfeat: fp32 [N][F].  Writes every backbone parameter gradient (accumulating)."""
+        dev = dfeat.device
+        sums_pool = _StatsPool(sum(cb.Co for cb in self.all_convbn()), dev)
+        shape = saved["final"][0]
+        N, To, Ho, Wo, Cf = shape
+        g = ops.gavgpool_bwd(dfeat.contiguous(), N, To * Ho * Wo, Cf, shape)
+        for (cbs, ds), (xin, recs, dsrec) in zip(reversed(self.blocks), reversed(saved["blocks"])):
+            # last conv of the block: BN + residual + ReLU
+            cb = cbs[-1]
+            d, h, y, prm, out = recs[-1]
+            dy, gres = ops.bn_bwd(y, g, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias), mask=1,
+                                  aux=out, want_g=True, sums=sums_pool.take(cb.Co))
+            self._ready(cb.bn.weight, cb.bn.bias)
+            ops.conv3d_wgrad(d, h, dy, self._gphys(cb.conv.weight))
+            self._ready(cb.conv.weight)
+            _, wd = cb.weights()
+            dz = ops.conv3d_dgrad(d, dy, wd)
+            del dy
+            # middle / first convs: BN + ReLU
+            for i in range(len(cbs) - 2, -1, -1):
+                cb = cbs[i]
+                d, h, y, prm, z = recs[i]
+                dy, _ = ops.bn_bwd(y, dz, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias), mask=1,
+                                   aux=z, sums=sums_pool.take(cb.Co))
+                self._ready(cb.bn.weight, cb.bn.bias)
+                if i == 0 and ds is not None:
+                    # downsample branch first so the first conv's dgrad can accumulate onto it
+                    dd, yd, prmd = dsrec
+                    dyd, _ = ops.bn_bwd(yd, gres, prmd, ds.Co, self.gview(ds.bn.weight), self.gview(ds.bn.bias),
+                                        mask=0, sums=sums_pool.take(ds.Co))
+                    self._ready(ds.bn.weight, ds.bn.bias)
+                    ops.conv3d_wgrad(dd, xin, dyd, self._gphys(ds.conv.weight))
+                    self._ready(ds.conv.weight)
+                    _, wdd = ds.weights()
+                    gres = ops.conv3d_dgrad(dd, dyd, wdd)
+                    del dyd
+                ops.conv3d_wgrad(d, h, dy, self._gphys(cb.conv.weight))
+                self._ready(cb.conv.weight)
+                _, wd = cb.weights()
+                if i == 0:
+                    dz = ops.conv3d_dgrad(d, dy, wd, out=gres, accumulate=True)
+                else:
+                    dz = ops.conv3d_dgrad(d, dy, wd)
+                del dy
+            g = dz
+        # stem: max pool -> BN+ReLU (mask recomputed) -> conv wgrad
+        xs, y0, p0, pd, idx, (N, T, H, W) = saved["stem"]
+        st = self.stem
+        din = ops.maxpool3d_bwd(pd, g, idx)
+        dy0, _ = ops.bn_bwd(y0, din, p0, st.Co, self.gview(st.bn.weight), self.gview(st.bn.bias), mask=2,
+                            sums=sums_pool.take(st.Co))
+        self._ready(st.bn.weight, st.bn.bias)
+        if self._stem_scratch is None or self._stem_scratch.device != dev or self._stem_scratch.shape[0] != st.Co:
+            self._stem_scratch = torch.zeros(st.Co, ops.STEM_K, dtype=F32, device=dev)
+        ops.stem_wgrad(xs, dy0, N, T, H, W, st.Co, self._gphys(st.conv.weight), scratch=self._stem_scratch)
+        self._ready(st.conv.weight)
+
+
+class _StatsPool:
+    """one zero-filled allocation carved into per-layer [R][2][C] accumulators."""
+
+    def __init__(self, total_channels, device):
+        self.buf = torch.zeros(total_channels * 2 * VC_STAT_REPLICAS, dtype=F32, device=device)
+        self.off = 0
+
+    def take(self, C):
+        n = VC_STAT_REPLICAS * 2 * C
+        if self.off + n > self.buf.numel():
+            raise Vc3dError("stats pool exhausted")
+        v = self.buf[self.off:self.off + n]
+        self.off += n
+        return v
