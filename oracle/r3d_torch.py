@@ -179,3 +179,106 @@ def synthetic_batch(n, t=16, h=112, w=112, classes=101, seed=1234):
     x = torch.randn(n, 3, t, h, w, generator=g)
     y = torch.randint(0, classes, (n,), generator=g)
     return x, y
+
+
+# --------------------------------------------------------------------------------------
+# bf16-storage emulation of the SAME network (still the oracle: plain torch on the CPU).
+#
+# The product keeps activations and activation-gradients in bf16 and accumulates in fp32.
+# Against the pure-fp32 oracle that shows up as ~1.5 % noise on late activations, and --
+# because ReLU's gradient mask is discontinuous -- as O(10 %) noise on gradients of a
+# randomly initialised net (about 1 % of the masks flip).  To test the kernels rather than
+# the number format, `forward_emulated` evaluates the oracle with a bf16 rounding at every
+# point where the product stores a tensor (conv output, BN/ReLU output, every gradient
+# tensor), fp32 everywhere else.  Agreement with it is expected at the 1e-3 level.
+def _rbf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundGrad(torch.autograd.Function):
+    """identity forward on already-bf16 values; rounds the gradient to bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rbf(g)
+
+
+class _BNActEmul(torch.autograd.Function):
+    """train-mode BatchNorm (+residual)(+ReLU) with the product's storage points: batch
+    statistics from the fp32 conv output, normalisation of its bf16 rounding, bf16 result;
+    backward with the standard batch-stat formula on the rounded incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, res, relu, bn):
+        dims = (0, 2, 3, 4)
+        mean = y.mean(dims)
+        var = (y * y).mean(dims) - mean * mean
+        var = var.clamp_min(0)
+        n = y.numel() // y.shape[1]
+        if bn is not None and bn.track_running_stats:
+            with torch.no_grad():
+                bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * mean)
+                bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * var * n / max(n - 1, 1))
+        invstd = torch.rsqrt(var + (bn.eps if bn is not None else 1e-5))
+        scale = gamma * invstd
+        shift = beta - mean * scale
+        sh = (1, -1, 1, 1, 1)
+        yr = _rbf(y)
+        v = yr * scale.view(sh) + shift.view(sh)
+        if res is not None:
+            v = v + res
+        if relu:
+            v = torch.relu(v)
+        out = _rbf(v)
+        ctx.save_for_backward(yr, mean, invstd, scale, out)
+        ctx.relu = relu
+        ctx.has_res = res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        yr, mean, invstd, scale, out = ctx.saved_tensors
+        sh = (1, -1, 1, 1, 1)
+        dims = (0, 2, 3, 4)
+        g = _rbf(dz)
+        if ctx.relu:
+            g = g * (out > 0).to(g.dtype)
+        xhat = (yr - mean.view(sh)) * invstd.view(sh)
+        n = yr.numel() // yr.shape[1]
+        s1 = g.sum(dims)
+        s2 = (g * xhat).sum(dims)
+        dy = _rbf(scale.view(sh) * (g - (s1 / n).view(sh) - xhat * (s2 / n).view(sh)))
+        return dy, s2, s1, (g if ctx.has_res else None), None, None
+
+
+def _conv_e(conv, x):
+    return nn.functional.conv3d(x, _rbf(conv.weight), None, conv.stride, conv.padding)
+
+
+def forward_emulated(model, x):
+    """logits of R3DOracle `model` (train mode) with the product's bf16 storage points."""
+    bb = model.backbone
+    h = _BNActEmul.apply(_conv_e(bb.conv1, _rbf(x)), bb.bn1.weight, bb.bn1.bias, None, True, bb.bn1)
+    h = _RoundGrad.apply(bb.maxpool(h))
+    for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4):
+        for blk in layer:
+            xin = h
+            if isinstance(blk, Bottleneck):
+                seq = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)]
+            else:
+                seq = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)]
+            for conv, bn in seq[:-1]:
+                h = _BNActEmul.apply(_conv_e(conv, h), bn.weight, bn.bias, None, True, bn)
+            if blk.downsample is not None:
+                r = _BNActEmul.apply(_conv_e(blk.downsample[0], xin), blk.downsample[1].weight,
+                                     blk.downsample[1].bias, None, False, blk.downsample[1])
+            else:
+                r = xin
+            conv, bn = seq[-1]
+            h = _BNActEmul.apply(_conv_e(conv, h), bn.weight, bn.bias, r, True, bn)
+    feat = h.mean(dim=(2, 3, 4))
+    return model.clf_head(feat)

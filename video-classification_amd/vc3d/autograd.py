@@ -13,8 +13,8 @@ from . import ops
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, engine, training, anchor, *params):
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        feat, saved = engine.forward(x, training, save=need_grad)
+        # `anchor` = whether activations must be kept (grad mode is off inside Function.forward)
+        feat, saved = engine.forward(x, training, save=bool(anchor))
         ctx.engine = engine
         ctx.saved = saved
         return feat
@@ -35,7 +35,8 @@ def backbone_apply(engine, x, training):
     engine._fn_params = params
     if engine.flat_grad is None or engine.flat_grad.device != params[0].device:
         engine.setup_grads(extra_first=getattr(engine, "head_params", ()))
-    return _BackboneFn.apply(x, engine, training, None, *params)
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    return _BackboneFn.apply(x, engine, training, need_grad, *params)
 
 
 class _LinearFn(torch.autograd.Function):

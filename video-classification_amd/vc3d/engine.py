@@ -75,6 +75,11 @@ class R3DEngine:
         self.grad_views = None
         self.grad_ready_cb = None  # set by the data-parallel wrapper: cb(param)
         self._stem_scratch = None
+        self.trace = None  # tests set this to {} to record every intermediate tensor per layer
+
+    def _t(self, name, **kw):
+        if self.trace is not None:
+            self.trace.setdefault(name, {}).update(kw)
 
     # ------------------------------------------------------------------ parameters
     def all_convbn(self):
@@ -215,6 +220,7 @@ class R3DEngine:
         pk, ps, pp = self.pool
         pd = ops.pool_desc(N, st.Co, T, H // 2, W // 2, pk, ps, pp)
         a0, idx = ops.maxpool3d_fwd(pd, y0, p0)
+        self._t("conv1", clip=x, y=y0, prm=p0, pooled=a0)
         saved = {"stem": (xs, y0, p0, pd, idx, (N, T, H, W)), "blocks": []} if save else None
         if not save:
             del xs, y0, idx
@@ -229,22 +235,26 @@ class R3DEngine:
                 if not last:
                     z = ops.bn_apply(y, prm, cb.Co, relu=True)
                     recs.append((d, h, y, prm, z))
+                    self._t(cb.name, x=h, y=y, prm=prm, out=z, res=None, relu=True)
                     h = z
                 else:
                     if ds is not None:
                         dd, yd, prmd = self._conv_bn(ds, xin, training, stats_pool)
                         r = ops.bn_apply(yd, prmd, ds.Co, relu=False)
+                        self._t(ds.name, x=xin, y=yd, prm=prmd, out=r, res=None, relu=False)
                     else:
                         dd = yd = prmd = None
                         r = xin
                     out = ops.bn_apply(y, prm, cb.Co, residual=r, relu=True)
                     recs.append((d, h, y, prm, out))
                     dsrec = (dd, yd, prmd)
+                    self._t(cb.name, x=h, y=y, prm=prm, out=out, res=r, relu=True)
             if save:
                 saved["blocks"].append((xin, recs, dsrec))
             cur = out
         Nn, To, Ho, Wo, Cf = cur.shape
         feat = ops.gavgpool_fwd(cur, Nn, To * Ho * Wo, Cf)
+        self._t("final", x=cur, feat=feat)
         if save:
             saved["final"] = (tuple(cur.shape),)
         return feat, saved
@@ -257,6 +267,7 @@ class R3DEngine:
         shape = saved["final"][0]
         N, To, Ho, Wo, Cf = shape
         g = ops.gavgpool_bwd(dfeat.contiguous(), N, To * Ho * Wo, Cf, shape)
+        self._t("final", dfeat=dfeat, dx=g)
         for (cbs, ds), (xin, recs, dsrec) in zip(reversed(self.blocks), reversed(saved["blocks"])):
             # last conv of the block: BN + residual + ReLU
             cb = cbs[-1]
@@ -268,6 +279,7 @@ class R3DEngine:
             self._ready(cb.conv.weight)
             _, wd = cb.weights()
             dz = ops.conv3d_dgrad(d, dy, wd)
+            self._t(cb.name, dz=g, dy=dy, gres=gres, dx=dz, dx_base=None)
             del dy
             # middle / first convs: BN + ReLU
             for i in range(len(cbs) - 2, -1, -1):
@@ -285,26 +297,35 @@ class R3DEngine:
                     ops.conv3d_wgrad(dd, xin, dyd, self._gphys(ds.conv.weight))
                     self._ready(ds.conv.weight)
                     _, wdd = ds.weights()
+                    dzd = gres
                     gres = ops.conv3d_dgrad(dd, dyd, wdd)
+                    self._t(ds.name, dz=dzd, dy=dyd, dx=gres.clone() if self.trace is not None else None,
+                            dx_base=None)
                     del dyd
                 ops.conv3d_wgrad(d, h, dy, self._gphys(cb.conv.weight))
                 self._ready(cb.conv.weight)
                 _, wd = cb.weights()
+                dz_in = dz
                 if i == 0:
+                    base = gres.clone() if self.trace is not None else None
                     dz = ops.conv3d_dgrad(d, dy, wd, out=gres, accumulate=True)
                 else:
+                    base = None
                     dz = ops.conv3d_dgrad(d, dy, wd)
+                self._t(cb.name, dz=dz_in, dy=dy, dx=dz, dx_base=base)
                 del dy
             g = dz
         # stem: max pool -> BN+ReLU (mask recomputed) -> conv wgrad
         xs, y0, p0, pd, idx, (N, T, H, W) = saved["stem"]
         st = self.stem
         din = ops.maxpool3d_bwd(pd, g, idx)
+        self._t("conv1", dpooled=g, dz=din)
         dy0, _ = ops.bn_bwd(y0, din, p0, st.Co, self.gview(st.bn.weight), self.gview(st.bn.bias), mask=2,
                             sums=sums_pool.take(st.Co))
         self._ready(st.bn.weight, st.bn.bias)
         if self._stem_scratch is None or self._stem_scratch.device != dev or self._stem_scratch.shape[0] != st.Co:
             self._stem_scratch = torch.zeros(st.Co, ops.STEM_K, dtype=F32, device=dev)
+        self._t("conv1", dy=dy0)
         ops.stem_wgrad(xs, dy0, N, T, H, W, st.Co, self._gphys(st.conv.weight), scratch=self._stem_scratch)
         self._ready(st.conv.weight)
 
