@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train clips/sec of the 3D-ResNet at 16x112x112 on N MI355X GPUs.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A step = forward + cross-entropy + backward + optimizer step on one synthetic batch that is
+already resident in HBM.  Rank 0 prints ONE JSON line (contract in the task statement) with
+two extra objects:
+  roofline     : the dominant kernel (largest share of conv time), timed live with HIP events
+                 on the launch stream inside the timed region; achieved = algorithmic FLOPs
+                 per launch / average launch duration, against the 2.5 PFLOP/s dense bf16 peak.
+  cpu_baseline : the oracle (stock torch.nn fp32 3D-ResNet-18, oracle/r3d_torch.py) timed on
+                 this box's host cores on a bounded sample (config 1: batch 8), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "video-classification_amd")
+for p in (ROOT, PKG, os.path.join(PKG, "lib")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (guide: ~2.5 PF dense)
+PEAK_HBM_GBS = 8000.0
+# fwd+bwd GFLOP per clip (contract figure, SURVEY.md 8(d) / BASELINE.md)
+GFLOP_PER_CLIP = {(18, 16, 112): 43.25, (50, 16, 112): 53.81}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", type=int, default=18, help="ResNet depth (18 = config 2, 50 = config 3)")
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--clip-len", type=int, default=16)
+    ap.add_argument("--crop", type=int, default=112)
+    ap.add_argument("--classes", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--eval", action="store_true", help="forward-only (valid.py path) throughput")
+    return ap.parse_args()
+
+
+def cpu_baseline(steps):
+    """oracle fp32 fwd+bwd+SGD step, 8x3x16x112x112, on the host cores (kind: port)."""
+    from oracle.r3d_torch import R3DOracle, init_weights_, synthetic_batch
+    model = init_weights_(R3DOracle(18, 101), 0).train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.001, momentum=0.9, weight_decay=1e-4)
+    x, y = synthetic_batch(8, 16, 112, 112, 101, 1234)
+
+    def step():
+        opt.zero_grad()
+        F.cross_entropy(model(x), y).backward()
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        step()
+    dt = (time.time() - t0) / steps
+    return {"value": 8.0 / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d timed steps (1 warm-up) of oracle R3D-18 fp32 fwd+bwd+SGD on 8x3x16x112x112, %s" %
+                      (steps, _cpu_model())}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    import vc3d
+    from vc3d import ops
+    from vc3d.ddp import DataParallel3D
+    from core.config import config
+    from core.loss import Loss
+    from models.model import create_model
+    from utils.utils import create_optimizer
+
+    cfg = config.clone()
+    cfg.MODEL.RESNET_TYPE = args.model
+    cfg.MODEL.CLFDIM = args.classes or (101 if args.model == 18 else 400)
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.TRAIN.OPTIMIZER = "sgd"
+    cfg.TRAIN.LR = 0.001
+    torch.manual_seed(0)
+    model = create_model(cfg, is_train=True).to(dev)
+    criterion = Loss(cfg).to(dev)
+    optimizer = create_optimizer(cfg, model)
+    net = DataParallel3D(model) if world > 1 else model
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(args.batch, 3, args.clip_len, args.crop, args.crop, generator=g).to(torch.bfloat16).to(dev)
+    y = torch.randint(0, cfg.MODEL.CLFDIM, (args.batch,), generator=g).to(dev)
+
+    if args.eval:
+        net.eval()
+
+        def step():
+            with torch.no_grad():
+                net(x)
+    else:
+        net.train()
+
+        def step():
+            _, score, _ = net(x)
+            loss = criterion(score, y, None, None)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+
+    # ---- warm-up; the last warm-up step times every conv launch to find the dominant kernel
+    for i in range(max(args.warmup, 1)):
+        if i == max(args.warmup, 1) - 1:
+            ops.TIMER = ops.KernelTimer()
+        step()
+    torch.cuda.synchronize()
+    table = ops.TIMER.summary()
+    ops.TIMER = None
+    dominant = max(table, key=lambda k: table[k][0] * table[k][1]) if table else None
+    if args.profile_kernels and rank == 0:
+        tot = sum(v[0] * v[1] for v in table.values())
+        for k, (n, ms, fl) in sorted(table.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            print("%-70s x%d %8.3f ms  %7.1f TFLOP/s  %5.1f%%" % (k, n, ms, fl / ms / 1e9, 100 * n * ms / tot),
+                  file=sys.stderr)
+        print("conv total %.3f ms per step" % tot, file=sys.stderr)
+
+    # ---- timed region
+    ops.TIMER = ops.KernelTimer(select=(lambda k: k == dominant)) if dominant is not None else None
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    roof = None
+    if ops.TIMER is not None:
+        summ = ops.TIMER.summary()
+        ops.TIMER = None
+        if dominant in summ:
+            n, ms, fl = summ[dominant]
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv3d %s %s" % (dominant[0], "x".join(str(v) for v in dominant[1:])),
+                    "launches_timed": n, "avg_ms": round(ms, 4), "flops_per_launch": fl}
+
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        value = clips / dt
+        gf = GFLOP_PER_CLIP.get((args.model, args.clip_len, args.crop))
+        out = {
+            "metric": "train clips/sec (whole node) 3D-ResNet 16x112x112" if not args.eval
+            else "inference clips/sec (whole node) 3D-ResNet forward-only",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "3D-ResNet-%d %s, synthetic %dx%dx%d clips, %d classes, batch %d per GPU, "
+                                   "SGD momentum" % (args.model, "forward-only" if args.eval else "bf16 training",
+                                                     args.clip_len, args.crop, args.crop, cfg.MODEL.CLFDIM,
+                                                     args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "roofline": roof,
+        }
+        if gf is not None and not args.eval:
+            out["mfma_frac_end_to_end"] = round(value * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
+        if world == 1 and not args.no_cpu_baseline and not args.eval:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -168,4 +168,4 @@ def test_r3d50_teacher_forced():
 
 
 def test_r3d34_teacher_forced_forward_only():
-    _run(34, 101, n=1, t=4, hw=32, backward=False)
+    _run(34, 101, n=2, t=4, hw=64, backward=False)

@@ -74,6 +74,7 @@ class R3DEngine:
         self.flat_grad = None
         self.grad_views = None
         self.grad_ready_cb = None  # set by the data-parallel wrapper: cb(param)
+        self.backward_done_cb = None
         self._stem_scratch = None
         self.trace = None  # tests set this to {} to record every intermediate tensor per layer
 
@@ -328,6 +329,8 @@ class R3DEngine:
         self._t("conv1", dy=dy0)
         ops.stem_wgrad(xs, dy0, N, T, H, W, st.Co, self._gphys(st.conv.weight), scratch=self._stem_scratch)
         self._ready(st.conv.weight)
+        if self.backward_done_cb is not None:
+            self.backward_done_cb()
 
 
 class _StatsPool:

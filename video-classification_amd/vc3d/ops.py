@@ -13,6 +13,44 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 
+class KernelTimer:
+    """HIP-event timing of individual launches on the current stream (bench.py / profiling only).
+    ``select`` is a predicate on the launch key (kind, shape...); None times every conv launch."""
+
+    def __init__(self, select=None):
+        self.select = select
+        self.records = {}  # key -> [flops_per_launch, [(start, end), ...]]
+
+    def begin(self, key, flops):
+        if self.select is not None and not self.select(key):
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.records.setdefault(key, [flops, []])[1].append((e0, e1))
+        return e1
+
+    def summary(self):
+        """{key: (launches, avg_ms, flops_per_launch)}; call after a device synchronize."""
+        out = {}
+        for key, (flops, evs) in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[key] = (len(ms), sum(ms) / max(len(ms), 1), flops)
+        return out
+
+
+TIMER = None  # set to a KernelTimer to time conv launches
+
+
+def _conv_key(kind, d):
+    return (kind, d.N, d.Ci, d.Ti, d.Hi, d.Wi, d.Co, d.kt, d.kh, d.kw, d.st, d.sh, d.sw)
+
+
+def _conv_flops(d):
+    To, Ho, Wo = d.out_dims()
+    return 2.0 * d.N * To * Ho * Wo * d.Co * d.Ci * d.kt * d.kh * d.kw
+
+
 def _chk(t, dtype, numel=None, name="tensor"):
     if t is None:
         return
@@ -59,7 +97,10 @@ def conv3d_fwd(d, x, wf, stats=None, out=None):
         out = torch.empty(d.N, To, Ho, Wo, d.Co, dtype=BF16, device=x.device)
     _chk(out, BF16, d.N * To * Ho * Wo * d.Co, "y")
     _chk(stats, F32, VC_STAT_REPLICAS * 2 * d.Co, "bn_stats")
+    ev = TIMER.begin(_conv_key("fwd", d), _conv_flops(d)) if TIMER is not None else None
     check(lib.vc_conv3d_fwd(d, ptr(x), ptr(wf), ptr(out), ptr(stats), cur_stream()), "vc_conv3d_fwd")
+    if ev is not None:
+        ev.record()
     return out
 
 
@@ -73,7 +114,10 @@ def conv3d_dgrad(d, dy, wd, out=None, accumulate=False):
             raise capi.Vc3dError("conv3d_dgrad: accumulate needs an existing dx")
         out = torch.empty(d.N, d.Ti, d.Hi, d.Wi, d.Ci, dtype=BF16, device=dy.device)
     _chk(out, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "dx")
+    ev = TIMER.begin(_conv_key("dgrad", d), _conv_flops(d)) if TIMER is not None else None
     check(lib.vc_conv3d_dgrad(d, ptr(dy), ptr(wd), ptr(out), 1 if accumulate else 0, cur_stream()), "vc_conv3d_dgrad")
+    if ev is not None:
+        ev.record()
     return out
 
 
@@ -84,7 +128,10 @@ def conv3d_wgrad(d, x, dy, dw):
     _chk(x, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "x")
     _chk(dy, BF16, d.N * To * Ho * Wo * d.Co, "dy")
     _chk(dw, F32, d.Co * taps * d.Ci, "dw")
+    ev = TIMER.begin(_conv_key("wgrad", d), _conv_flops(d)) if TIMER is not None else None
     check(lib.vc_conv3d_wgrad(d, ptr(x), ptr(dy), ptr(dw), cur_stream()), "vc_conv3d_wgrad")
+    if ev is not None:
+        ev.record()
     return dw
 
 
@@ -121,7 +168,11 @@ def stem_fwd(xs, ws, N, T, H, W, Co, stats=None, out=None):
         out = torch.empty(N, T, H // 2, W // 2, Co, dtype=BF16, device=xs.device)
     _chk(out, BF16, N * T * (H // 2) * (W // 2) * Co, "y")
     _chk(stats, F32, VC_STAT_REPLICAS * 2 * Co, "bn_stats")
+    flops = 2.0 * N * T * (H // 2) * (W // 2) * Co * 1029
+    ev = TIMER.begin(("stem_fwd", N, T, H, W, Co), flops) if TIMER is not None else None
     check(lib.vc_stem_fwd(ptr(xs), ptr(ws), ptr(out), ptr(stats), N, T, H, W, Co, cur_stream()), "vc_stem_fwd")
+    if ev is not None:
+        ev.record()
     return out
 
 
@@ -135,7 +186,11 @@ def stem_wgrad(xs, dy, N, T, H, W, Co, dw_master_phys, scratch=None):
     else:
         _chk(scratch, F32, Co * STEM_K, "stem wgrad scratch")
         scratch.zero_()
+    flops = 2.0 * N * T * (H // 2) * (W // 2) * Co * 1029
+    ev = TIMER.begin(("stem_wgrad", N, T, H, W, Co), flops) if TIMER is not None else None
     check(lib.vc_stem_wgrad(ptr(xs), ptr(dy), ptr(scratch), N, T, H, W, Co, cur_stream()), "vc_stem_wgrad")
+    if ev is not None:
+        ev.record()
     check(lib.vc_stem_unpack_wgrad(ptr(scratch), ptr(dw_master_phys), Co, cur_stream()), "vc_stem_unpack_wgrad")
     return dw_master_phys
 
