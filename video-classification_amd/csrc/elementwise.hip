@@ -513,17 +513,29 @@ inline int grid_for(long n, int block = 256, int cap = 256 * 16) {
 
 }  // namespace
 
-#define VC_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : (vc_set_error("kernel launch failed"), -1))
+// drop any stale error another user of the runtime (torch) left behind, then launch
+#define VC_LAUNCH(...)                  \
+    do {                                \
+        (void)hipGetLastError();        \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+static inline int vc_check_launch() {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    vc_set_error("kernel launch failed: %s", hipGetErrorString(e));
+    return -1;
+}
+#define VC_CHECK_LAUNCH() vc_check_launch()
 
 int vc_ew_bn_finalize(const float* stats, int C, float count, const float* gamma, const float* beta, float* rmean,
                       float* rvar, float momentum, float eps, float* params, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, C, count, gamma, beta, rmean,
+    VC_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, C, count, gamma, beta, rmean,
                        rvar, momentum, eps, params);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_eval_params(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
                          float* params, hipStream_t s) {
-    hipLaunchKernelGGL(bn_eval_params_kernel, dim3((C + 255) / 256), dim3(256), 0, s, C, gamma, beta, rmean, rvar, eps,
+    VC_LAUNCH(bn_eval_params_kernel, dim3((C + 255) / 256), dim3(256), 0, s, C, gamma, beta, rmean, rvar, eps,
                        params);
     return VC_CHECK_LAUNCH();
 }
@@ -535,13 +547,13 @@ int vc_ew_bn_apply(const void* y, const float* params, const void* res, void* ou
     const bf16x8* rr = (const bf16x8*)res;
     bf16x8* oo = (bf16x8*)out;
     if (res && relu)
-        hipLaunchKernelGGL((bn_apply_kernel<true, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+        VC_LAUNCH((bn_apply_kernel<true, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
     else if (res)
-        hipLaunchKernelGGL((bn_apply_kernel<true, false>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+        VC_LAUNCH((bn_apply_kernel<true, false>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
     else if (relu)
-        hipLaunchKernelGGL((bn_apply_kernel<false, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+        VC_LAUNCH((bn_apply_kernel<false, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
     else
-        hipLaunchKernelGGL((bn_apply_kernel<false, false>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+        VC_LAUNCH((bn_apply_kernel<false, false>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
     return VC_CHECK_LAUNCH();
 }
 
@@ -557,7 +569,7 @@ static void reduce_geometry(long rows, int C, int& grid, int& rpb) {
 int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, hipStream_t s) {
     int grid, rpb;
     reduce_geometry(rows, C, grid, rpb);
-    hipLaunchKernelGGL((chan_reduce_kernel<0, 0>), dim3(grid), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)nullptr,
+    VC_LAUNCH((chan_reduce_kernel<0, 0>), dim3(grid), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)nullptr,
                        (const bf16x8*)nullptr, (const float*)nullptr, sums, rows, C, rpb);
     return VC_CHECK_LAUNCH();
 }
@@ -567,16 +579,16 @@ int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const fl
     reduce_geometry(rows, C, grid, rpb);
     const bf16x8 *yy = (const bf16x8*)y, *dd = (const bf16x8*)dz, *aa = (const bf16x8*)aux;
     if (mask == 0)
-        hipLaunchKernelGGL((chan_reduce_kernel<1, 0>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
+        VC_LAUNCH((chan_reduce_kernel<1, 0>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
     else if (mask == 1)
-        hipLaunchKernelGGL((chan_reduce_kernel<1, 1>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
+        VC_LAUNCH((chan_reduce_kernel<1, 1>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
     else
-        hipLaunchKernelGGL((chan_reduce_kernel<1, 2>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
+        VC_LAUNCH((chan_reduce_kernel<1, 2>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_bwd_finalize(const float* sums, int C, float count, float* coef, float* dgamma, float* dbeta,
                           hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, count, coef, dgamma,
+    VC_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, count, coef, dgamma,
                        dbeta);
     return VC_CHECK_LAUNCH();
 }
@@ -587,7 +599,7 @@ int vc_ew_bn_bwd_apply(const void* y, const void* dz, const void* aux, const flo
     const bf16x8 *yy = (const bf16x8*)y, *dd = (const bf16x8*)dz, *aa = (const bf16x8*)aux;
     bf16x8 *oo = (bf16x8*)dy, *gg = (bf16x8*)gout;
 #define VC_BWD_APPLY(M, G) \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<M, G>), dim3(g), dim3(256), 0, s, yy, dd, aa, params, coef, oo, gg, n8, C)
+    VC_LAUNCH((bn_bwd_apply_kernel<M, G>), dim3(g), dim3(256), 0, s, yy, dd, aa, params, coef, oo, gg, n8, C)
     if (gout) {
         if (mask == 0) VC_BWD_APPLY(0, true);
         else if (mask == 1) VC_BWD_APPLY(1, true);
@@ -602,88 +614,88 @@ int vc_ew_bn_bwd_apply(const void* y, const void* dz, const void* aux, const flo
 }
 int vc_ew_add(const void* a, const void* b, void* out, long n, hipStream_t s) {
     const long n8 = n / 8;
-    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n8)), dim3(256), 0, s, (const bf16x8*)a, (const bf16x8*)b, (bf16x8*)out,
+    VC_LAUNCH(add_kernel, dim3(grid_for(n8)), dim3(256), 0, s, (const bf16x8*)a, (const bf16x8*)b, (bf16x8*)out,
                        n8);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_maxpool_fwd(const void* y, const float* params, void* out, uint8_t* idx, const VcPoolGeom& g, hipStream_t s) {
     const long total = (long)g.N * g.To * g.Ho * g.Wo * (g.C / 8);
     if (params)
-        hipLaunchKernelGGL((maxpool_fwd_kernel<true>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16x8*)y, params,
+        VC_LAUNCH((maxpool_fwd_kernel<true>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16x8*)y, params,
                            (bf16x8*)out, idx, g);
     else
-        hipLaunchKernelGGL((maxpool_fwd_kernel<false>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16x8*)y, params,
+        VC_LAUNCH((maxpool_fwd_kernel<false>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16x8*)y, params,
                            (bf16x8*)out, idx, g);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_maxpool_bwd(const void* dout, const uint8_t* idx, void* din, const VcPoolGeom& g, hipStream_t s) {
     const long total = (long)g.N * g.T * g.H * g.W * (g.C / 8);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const bf16x8*)dout, idx, (bf16x8*)din,
+    VC_LAUNCH(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const bf16x8*)dout, idx, (bf16x8*)din,
                        g);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_avgpool_fwd(const void* in, float* out, int N, int S, int C, hipStream_t s) {
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, (const bf16*)in, out, N, S, C);
+    VC_LAUNCH(avgpool_fwd_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, (const bf16*)in, out, N, S, C);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_avgpool_bwd(const float* dfeat, void* din, int N, int S, int C, hipStream_t s) {
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)N * S * C)), dim3(256), 0, s, dfeat, (bf16*)din, N, S, C);
+    VC_LAUNCH(avgpool_bwd_kernel, dim3(grid_for((long)N * S * C)), dim3(256), 0, s, dfeat, (bf16*)din, N, S, C);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_linear_fwd(const float* feat, const float* W, const float* bias, float* out, int N, int F, int K,
                      hipStream_t s) {
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3((N * K + 3) / 4), dim3(256), 0, s, feat, W, bias, out, N, F, K);
+    VC_LAUNCH(linear_fwd_kernel, dim3((N * K + 3) / 4), dim3(256), 0, s, feat, W, bias, out, N, F, K);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_linear_bwd(const float* dlog, const float* feat, const float* W, float* dfeat, float* dW, float* db, int N,
                      int F, int K, hipStream_t s) {
     if (dfeat)
-        hipLaunchKernelGGL(linear_bwd_data_kernel, dim3((N * F + 255) / 256), dim3(256), 0, s, dlog, W, dfeat, N, F, K);
+        VC_LAUNCH(linear_bwd_data_kernel, dim3((N * F + 255) / 256), dim3(256), 0, s, dlog, W, dfeat, N, F, K);
     if (dW)
-        hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3((K * F + 255) / 256), dim3(256), 0, s, dlog, feat, dW, db, N, F,
+        VC_LAUNCH(linear_bwd_weight_kernel, dim3((K * F + 255) / 256), dim3(256), 0, s, dlog, feat, dW, db, N, F,
                            K);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_stem_pack_input(const void* x, int x_is_bf16, void* xs, int N, int T, int H, int W, hipStream_t s) {
     const long total = (long)N * (T + 6) * (H / 2 + 3) * (W / 2 + 3);
     if (x_is_bf16)
-        hipLaunchKernelGGL((stem_pack_input_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)x,
+        VC_LAUNCH((stem_pack_input_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)x,
                            (bf16*)xs, N, T, H, W);
     else
-        hipLaunchKernelGGL((stem_pack_input_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)x,
+        VC_LAUNCH((stem_pack_input_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)x,
                            (bf16*)xs, N, T, H, W);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_ncs_to_nsc(const void* in, int in_is_bf16, void* out, int N, int C, long S, hipStream_t s) {
     const long total = (long)N * C * S;
     if (in_is_bf16)
-        hipLaunchKernelGGL((ncs_to_nsc_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in, (bf16*)out,
+        VC_LAUNCH((ncs_to_nsc_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in, (bf16*)out,
                            N, C, S);
     else
-        hipLaunchKernelGGL((ncs_to_nsc_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)in,
+        VC_LAUNCH((ncs_to_nsc_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)in,
                            (bf16*)out, N, C, S);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_nsc_to_ncs(const void* in, void* out, int out_is_bf16, int N, int C, long S, hipStream_t s) {
     const long total = (long)N * C * S;
     if (out_is_bf16)
-        hipLaunchKernelGGL((nsc_to_ncs_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in, (bf16*)out,
+        VC_LAUNCH((nsc_to_ncs_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in, (bf16*)out,
                            N, C, S);
     else
-        hipLaunchKernelGGL((nsc_to_ncs_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in,
+        VC_LAUNCH((nsc_to_ncs_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in,
                            (float*)out, N, C, S);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_pack_weight(const float* w, void* wf, void* wd, int Co, int taps, int Ci, hipStream_t s) {
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for((long)Co * taps * Ci)), dim3(256), 0, s, w, (bf16*)wf, (bf16*)wd,
+    VC_LAUNCH(pack_weight_kernel, dim3(grid_for((long)Co * taps * Ci)), dim3(256), 0, s, w, (bf16*)wf, (bf16*)wd,
                        Co, taps, Ci);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_stem_pack_weight(const float* w, void* ws, int Co, hipStream_t s) {
-    hipLaunchKernelGGL(stem_pack_weight_kernel, dim3((Co * 1344 + 255) / 256), dim3(256), 0, s, w, (bf16*)ws, Co);
+    VC_LAUNCH(stem_pack_weight_kernel, dim3((Co * 1344 + 255) / 256), dim3(256), 0, s, w, (bf16*)ws, Co);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_stem_unpack_wgrad(const float* dws, float* dw, int Co, hipStream_t s) {
-    hipLaunchKernelGGL(stem_unpack_wgrad_kernel, dim3((Co * 1344 + 255) / 256), dim3(256), 0, s, dws, dw, Co);
+    VC_LAUNCH(stem_unpack_wgrad_kernel, dim3((Co * 1344 + 255) / 256), dim3(256), 0, s, dws, dw, Co);
     return VC_CHECK_LAUNCH();
 }

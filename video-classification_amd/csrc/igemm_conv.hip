@@ -261,8 +261,14 @@ template <int BCO, int BM, int MODE>
 int launch_igemm(const VcIgemmParams& p, hipStream_t stream) {
     using Cfg = IgemmCfg<BCO, BM>;
     dim3 grid((p.M + BM - 1) / BM, p.Cn / BCO, 1);
+    (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL((igemm_kernel<BCO, BM, MODE>), grid, dim3(256), Cfg::LDS_BYTES, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        vc_set_error("igemm launch failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
 }
 
 }  // namespace

@@ -28,13 +28,6 @@ struct WgCfg {
     static_assert((BCO / 64) * NB == 4, "4 waves per workgroup");
 };
 
-__device__ __forceinline__ bf16x8 tr_frag(const char* base) {
-    // base: this lane's block-row address for the first read; second read is 16 rows below
-    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base));
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, lo, 0, 1, 2, 3, 0, 1, 2, 3));
-}
-
 template <int BCO, int NB, int MODE>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
     using Cfg = WgCfg<BCO, NB>;
@@ -232,8 +225,14 @@ int launch_wgrad(const VcWgradParams& p, int splits, hipStream_t stream) {
     using Cfg = WgCfg<BCO, NB>;
     const int nblk = (MODE == 0) ? p.ntaps * (p.Cs / 64) : p.Kw / 64;
     dim3 grid((nblk + NB - 1) / NB, p.Co / BCO, splits);
+    (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL((wgrad_kernel<BCO, NB, MODE>), grid, dim3(256), Cfg::LDS_BYTES, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        vc_set_error("wgrad launch failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
 }
 
 }  // namespace
