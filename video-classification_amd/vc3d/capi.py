@@ -6,6 +6,12 @@ is missing or a symbol does not resolve, importing fails loudly.
 import ctypes as C
 import os
 
+# torch must be imported BEFORE libvc3d.so is loaded: the library has to bind to the HIP runtime
+# that torch ships (one runtime per process, shared streams and device memory).  Loading
+# /opt/rocm's runtime first leaves the process with two half-initialised runtimes
+# ("no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvc3d.so")
 
@@ -110,5 +116,4 @@ def ptr(t):
 
 
 def cur_stream():
-    import torch
     return torch.cuda.current_stream().cuda_stream
