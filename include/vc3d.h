@@ -53,12 +53,20 @@ int vc_abi_version(void);
  * :131-132 (downsample 1x1) -- forward, and autograd's dgrad/wgrad of the same calls
  * (reference lib/core/function.py:81 loss.backward()). kt*kh*kw <= 32. */
 int vc_conv3d_out_dims(const vc_conv3d_desc* d, int32_t* To, int32_t* Ho, int32_t* Wo);
+/* `workspace` (device, caller-owned, nullable) holds the fp32 partial slabs of the split-K form used
+ * when the plain grid would not fill the chip; vc_conv3d_workspace_bytes(d, op) reports the need
+ * (op: 0 forward, 1 dgrad, 2 wgrad; 0 bytes = never used).  Without it the unsplit kernel runs
+ * (wgrad: float atomics).  With it results are bitwise reproducible. */
+size_t vc_conv3d_workspace_bytes(const vc_conv3d_desc* d, int32_t op);
 int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y,
-                  float* bn_stats /* nullable: fused sum / sum-of-squares of y */, void* stream);
+                  float* bn_stats /* nullable: fused sum / sum-of-squares of y */, void* workspace,
+                  size_t ws_bytes, void* stream);
 int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx,
-                    int accumulate /* dx += instead of dx = */, void* stream);
+                    int accumulate /* dx += instead of dx = */, void* workspace, size_t ws_bytes,
+                    void* stream);
 int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy,
-                    float* dw /* fp32 [Co][kt][kh][kw][Ci], += */, void* stream);
+                    float* dw /* fp32 [Co][kt][kh][kw][Ci], += */, void* workspace, size_t ws_bytes,
+                    void* stream);
 int vc_pack_weight(const float* w_master, void* w_fwd, void* w_dgrad /* nullable */, int32_t Co,
                    int32_t taps, int32_t Ci, void* stream);
 

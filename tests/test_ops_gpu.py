@@ -57,12 +57,25 @@ CONV_CASES = [
     (2, 64, 1, 6, 6, 64, 3, 1, 1),     # T = 1 (centre-tap regime)
     (2, 64, 1, 7, 7, 128, 3, 2, 1),
     (1, 512, 1, 4, 4, 512, 3, 1, 1),
+    (8, 256, 2, 7, 7, 256, 3, 1, 1),   # split-K forward / dgrad (few tiles, long K)
+    (8, 128, 4, 14, 14, 256, 3, 2, 1), # split-K over stride-parity classes
+    (16, 512, 1, 4, 4, 512, 3, 1, 1),
 ]
 
 
+@pytest.mark.parametrize("use_ws", [True, False])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv3d_fwd_dgrad_wgrad(case):
+def test_conv3d_fwd_dgrad_wgrad(case, use_ws):
     _need_gpu()
+    from vc3d import ops
+    ops.USE_WORKSPACE = use_ws  # False: no split-K slabs (direct kernels, atomics in wgrad)
+    try:
+        _conv_case(case)
+    finally:
+        ops.USE_WORKSPACE = True
+
+
+def _conv_case(case):
     from vc3d import ops
     N, Ci, T, H, W, Co, k, s, p = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))

@@ -71,7 +71,60 @@ int vc_conv3d_out_dims(const vc_conv3d_desc* d, int32_t* To, int32_t* Ho, int32_
     return 0;
 }
 
-int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, void* stream) {
+static int fwd_nchunks(const vc_conv3d_desc* d) { return d->kt * d->kh * d->kw * (d->Ci / 64); }
+
+// largest tap count over the stride-parity classes of the data gradient
+static int dgrad_max_taps(const vc_conv3d_desc* d, bool* has_empty_class) {
+    int best = 0;
+    bool empty = false;
+    for (int rt = 0; rt < d->st; ++rt)
+        for (int rh = 0; rh < d->sh; ++rh)
+            for (int rw = 0; rw < d->sw; ++rw) {
+                int cnt = 0;
+                for (int a = 0; a < d->kt; ++a)
+                    for (int b = 0; b < d->kh; ++b)
+                        for (int c = 0; c < d->kw; ++c)
+                            if ((((rt + d->pt - a) % d->st) + d->st) % d->st == 0 &&
+                                (((rh + d->ph - b) % d->sh) + d->sh) % d->sh == 0 &&
+                                (((rw + d->pw - c) % d->sw) + d->sw) % d->sw == 0)
+                                ++cnt;
+                if (cnt == 0) empty = true;
+                if (cnt > best) best = cnt;
+            }
+    if (has_empty_class) *has_empty_class = empty;
+    return best;
+}
+
+static int dgrad_splits(const vc_conv3d_desc* d) {
+    bool empty = false;
+    const int taps = dgrad_max_taps(d, &empty);
+    if (empty) return 1;  // a class with no tap is zero-filled, not computed: keep the direct path
+    const int Ta = (d->Ti + d->st - 1) / d->st, Ha = (d->Hi + d->sh - 1) / d->sh, Wa = (d->Wi + d->sw - 1) / d->sw;
+    return vc_igemm_splits(d->N * Ta * Ha * Wa, d->Ci, taps * (d->Co / 64));
+}
+
+size_t vc_conv3d_workspace_bytes(const vc_conv3d_desc* d, int32_t op) {
+    int To, Ho, Wo;
+    if (conv_check(d, To, Ho, Wo)) return 0;
+    if (op == 0) {
+        const int s = vc_igemm_splits(d->N * To * Ho * Wo, d->Co, fwd_nchunks(d));
+        return s > 1 ? (size_t)s * d->N * To * Ho * Wo * d->Co * 4 : 0;
+    }
+    if (op == 1) {
+        const int s = dgrad_splits(d);
+        return s > 1 ? (size_t)s * d->N * d->Ti * d->Hi * d->Wi * d->Ci * 4 : 0;
+    }
+    if (op == 2) {
+        int rps;
+        const int taps = d->kt * d->kh * d->kw;
+        const int s = vc_wgrad_splits(d->N * To * Ho * Wo, d->Co, taps * (d->Ci / 64), &rps);
+        return s > 1 ? (size_t)s * d->Co * taps * d->Ci * 4 : 0;
+    }
+    return 0;
+}
+
+int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, void* workspace,
+                  size_t ws_bytes, void* stream) {
     int To, Ho, Wo;
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
@@ -101,6 +154,18 @@ int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y
                 t.src_off = ((t.ot * d->Hi + t.oh) * d->Wi + t.ow) * d->Ci;
                 t.wk_off = i * d->Ci;
             }
+    const int splits = vc_igemm_splits(p.M, p.Cn, fwd_nchunks(d));
+    const size_t out_e = (size_t)p.M * d->Co;
+    if (splits > 1 && workspace != nullptr && ws_bytes >= (size_t)splits * out_e * 4) {
+        p.splits = splits;
+        p.cps = (fwd_nchunks(d) + splits - 1) / splits;
+        p.partial = (float*)workspace;
+        p.partial_stride = (long long)out_e;
+        p.stats = nullptr;
+        rc = vc_launch_igemm(p, 0, S(stream));
+        if (rc) return rc;
+        return vc_ew_splitk_finalize(p.partial, splits, p.partial_stride, y, 0, bn_stats, p.M, d->Co, S(stream));
+    }
     return vc_launch_igemm(p, 0, S(stream));
 }
 
@@ -108,12 +173,15 @@ static inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b -
 static inline int posmod(int a, int b) { return ((a % b) + b) % b; }
 
 int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
-                    void* stream) {
+                    void* workspace, size_t ws_bytes, void* stream) {
     int To, Ho, Wo;
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(dy && w_dgrad && dx, "conv3d_dgrad: null pointer");
     const int ntaps_all = d->kt * d->kh * d->kw;
+    const size_t dx_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
+    int splits = dgrad_splits(d);
+    if (splits > 1 && (workspace == nullptr || ws_bytes < (size_t)splits * dx_e * 4)) splits = 1;
     // a parity class with no contributing tap gets zeros
     bool need_zero = false;
     if (!accumulate) {
@@ -175,13 +243,24 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
                         }
                 p.ntaps = n;
                 if (n == 0) continue;
+                if (splits > 1) {
+                    const int nchunks = n * (d->Co / 64);
+                    p.splits = splits;
+                    p.cps = (nchunks + splits - 1) / splits;
+                    p.partial = (float*)workspace;
+                    p.partial_stride = (long long)dx_e;
+                }
                 rc = vc_launch_igemm(p, 0, S(stream));
                 if (rc) return rc;
             }
+    if (splits > 1)
+        return vc_ew_splitk_finalize((const float*)workspace, splits, (long long)dx_e, dx, accumulate, nullptr,
+                                     (long)(dx_e / d->Ci), d->Ci, S(stream));
     return 0;
 }
 
-int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, float* dw, void* stream) {
+int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, float* dw, void* workspace,
+                    size_t ws_bytes, void* stream) {
     int To, Ho, Wo;
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
@@ -208,6 +287,16 @@ int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, floa
                 t.src_off = ((t.ot * d->Hi + t.oh) * d->Wi + t.ow) * d->Ci;
                 t.wk_off = i * d->Ci;
             }
+    int rps;
+    const int splits = vc_wgrad_splits(p.M, p.Co, p.ntaps * (d->Ci / 64), &rps);
+    const size_t dw_e = (size_t)d->Co * p.Kw;
+    if (splits > 1 && workspace != nullptr && ws_bytes >= (size_t)splits * dw_e * 4) {
+        p.partial = (float*)workspace;
+        p.partial_stride = (long long)dw_e;
+        rc = vc_launch_wgrad(p, 0, S(stream));
+        if (rc) return rc;
+        return vc_ew_splitk_reduce_wgrad(p.partial, splits, p.partial_stride, dw, (long)dw_e, S(stream));
+    }
     return vc_launch_wgrad(p, 0, S(stream));
 }
 

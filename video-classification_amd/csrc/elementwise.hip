@@ -163,6 +163,85 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restri
     }
 }
 
+// ------------------------------------------------------------------ split-K finalize
+// sum the fp32 slabs of a split-K conv -> bf16 activation (optionally += the existing value)
+// and, optionally, the BatchNorm sum / sum-of-squares of the unrounded result.
+template <bool STATS>
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ slabs, int splits,
+                                                              long long stride, bf16x8* __restrict__ out,
+                                                              int accumulate, float* stats, long rows, int C,
+                                                              int rows_per_block) {
+    __shared__ float sm[STATS ? 256 * 17 : 1];
+    const int groups = C >> 3;
+    const int rl = 256 / groups;
+    const int g = threadIdx.x % groups;
+    const int r = threadIdx.x / groups;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
+    const long row0 = (long)blockIdx.x * rows_per_block;
+    long row1 = row0 + rows_per_block;
+    if (row1 > rows) row1 = rows;
+    if (r < rl) {
+        for (long row = row0 + r; row < row1; row += rl) {
+            const long i = row * groups + g;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = 0.f;
+            for (int z = 0; z < splits; ++z) {
+                const f32x4* src = (const f32x4*)(slabs + (size_t)z * stride + i * 8);
+                const f32x4 lo = src[0], hi = src[1];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] += lo[k];
+                    v[4 + k] += hi[k];
+                }
+            }
+            if (accumulate) {
+                float o[8];
+                unpack8(out[i], o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += o[k];
+            }
+            out[i] = pack8(v);
+            if (STATS) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    a0[k] += v[k];
+                    a1[k] += v[k] * v[k];
+                }
+            }
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sm[threadIdx.x * 17 + k] = a0[k];
+            sm[threadIdx.x * 17 + 8 + k] = a1[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < groups) {
+            float* dst = stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * C;
+            for (int k = 0; k < 16; ++k) {
+                float s = 0.f;
+                for (int rr = 0; rr < rl; ++rr) s += sm[(rr * groups + threadIdx.x) * 17 + k];
+                atomicAdd(dst + (k < 8 ? 0 : C) + threadIdx.x * 8 + (k & 7), s);
+            }
+        }
+    }
+}
+
+// dw += sum over slabs (deterministic split-K reduction of the weight gradient)
+__global__ __launch_bounds__(256) void splitk_reduce_wgrad_kernel(const float* __restrict__ slabs, int splits,
+                                                                  long long stride, float* __restrict__ dw, long n4) {
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) {
+        f32x4 s = ((const f32x4*)dw)[i];
+        for (int z = 0; z < splits; ++z) s += ((const f32x4*)(slabs + (size_t)z * stride))[i];
+        ((f32x4*)dw)[i] = s;
+    }
+}
+
 // BN backward finalize: sums [R][2][C] -> coef [2][C] = (sum g)/n, (sum g xhat)/n ; dgamma += sum g xhat ; dbeta += sum g
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, float count, float* coef, float* dgamma,
                                        float* dbeta) {
@@ -584,6 +663,22 @@ int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const fl
         VC_LAUNCH((chan_reduce_kernel<1, 1>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
     else
         VC_LAUNCH((chan_reduce_kernel<1, 2>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void* out, int accumulate, float* stats,
+                          long rows, int C, hipStream_t s) {
+    int grid, rpb;
+    reduce_geometry(rows, C, grid, rpb);
+    if (stats)
+        VC_LAUNCH((splitk_finalize_kernel<true>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
+                  accumulate, stats, rows, C, rpb);
+    else
+        VC_LAUNCH((splitk_finalize_kernel<false>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
+                  accumulate, stats, rows, C, rpb);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, hipStream_t s) {
+    VC_LAUNCH(splitk_reduce_wgrad_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, slabs, splits, stride, dw, n / 4);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_bwd_finalize(const float* sums, int C, float count, float* coef, float* dgamma, float* dbeta,

@@ -159,18 +159,29 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    int cbeg = 0, cend = nchunks;
+    if (p.splits > 1) {
+        cbeg = blockIdx.z * p.cps;
+        cend = min(nchunks, cbeg + p.cps);
+    }
     int ti = 0, c0 = 0;
-    load_chunk(0, 0, 0);
-    store_chunk();
+    if (MODE == 0) {
+        ti = cbeg / cpt;
+        c0 = (cbeg - ti * cpt) * 64;
+    }
+    if (cbeg < cend) {
+        load_chunk(ti, c0, cbeg);
+        store_chunk();
+    }
     __syncthreads();
 
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = cbeg; c < cend; ++c) {
         int nti = ti, nc0 = c0 + 64;
         if (MODE == 0 && nc0 >= p.Cs) {
             nc0 = 0;
             nti = ti + 1;
         }
-        const bool more = (c + 1 < nchunks);
+        const bool more = (c + 1 < cend);
         if (more) load_chunk(nti, nc0, c + 1);
 
 #pragma unroll
@@ -204,6 +215,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) ooff[b] = sOutOff[wm * 64 + b * 16 + l15];
     const int cobase = co0 + wco * 64 + lg * 4;
+
+    if (p.partial != nullptr) {
+        float* slab = p.partial + (size_t)blockIdx.z * p.partial_stride;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (ooff[b] < 0) continue;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) *(f32x4*)(slab + (size_t)ooff[b] + cobase + a * 16) = acc[a][b];
+        }
+        return;
+    }
 
     if (p.stats != nullptr) {
         float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
@@ -260,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
 template <int BCO, int BM, int MODE>
 int launch_igemm(const VcIgemmParams& p, hipStream_t stream) {
     using Cfg = IgemmCfg<BCO, BM>;
-    dim3 grid((p.M + BM - 1) / BM, p.Cn / BCO, 1);
+    dim3 grid((p.M + BM - 1) / BM, p.Cn / BCO, p.splits > 1 ? p.splits : 1);
     (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL((igemm_kernel<BCO, BM, MODE>), grid, dim3(256), Cfg::LDS_BYTES, stream, p);
     const hipError_t e = hipGetLastError();
@@ -272,6 +294,16 @@ int launch_igemm(const VcIgemmParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+int vc_igemm_splits(int M, int Cn, int nchunks) {
+    const bool wide = (Cn % 128 == 0);
+    const long wgs = (long)((M + (wide ? 127 : 255)) / (wide ? 128 : 256)) * (Cn / (wide ? 128 : 64));
+    if (wgs >= 384 || nchunks < 8) return 1;
+    long s = (768 + wgs - 1) / wgs;
+    if (s > nchunks / 4) s = nchunks / 4;
+    if (s > 32) s = 32;
+    return s < 2 ? 1 : (int)s;
+}
 
 // Host dispatch.  mode 0 = tap table, 1 = stem.
 int vc_launch_igemm(const VcIgemmParams& p, int mode, hipStream_t stream) {

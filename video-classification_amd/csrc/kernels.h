@@ -14,6 +14,11 @@ struct VcIgemmParams {
     int ntaps, Kw, Cn;
     int out_n, out_t, out_h, out_w, out_base;
     int accumulate;
+    // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps); partial sums go to fp32 slabs
+    // partial[z][same element offsets as out]; a finalize kernel sums, rounds and takes BN statistics
+    int splits, cps;
+    float* partial;
+    long long partial_stride;
     VcTap taps[32];
 };
 
@@ -27,8 +32,14 @@ struct VcWgradParams {
     int st, sh, sw;
     int ntaps, Kw, Co;
     int rows_per_split;  // multiple of 64
+    int splits;
+    float* partial;  // nullable: fp32 slabs [splits][Co][Kw] instead of atomics
+    long long partial_stride;
     VcTap taps[32];
 };
 
 int vc_launch_igemm(const VcIgemmParams& p, int mode, hipStream_t stream);
 int vc_launch_wgrad(const VcWgradParams& p, int mode, hipStream_t stream);
+// split-K planning (shared by the workspace query and the launch)
+int vc_igemm_splits(int M, int Cn, int nchunks);
+int vc_wgrad_splits(int M, int Co, int nblk, int* rows_per_split);

@@ -200,7 +200,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
     }
 
     // ---- epilogue: acc[a][b][j] = dW[co0 + wco*64 + a*16 + lg*4 + j][col(wb) + b*16 + l15]
-    if (nchunks <= 0) return;
     bool okb = false;
     int colb = 0;
 #pragma unroll
@@ -210,13 +209,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
             colb = b_col[b];
         }
     if (!okb) return;
+    float* dst = p.dw;
+    int how = 0;  // 0 atomics, 1 plain += (single split owns the element), 2 plain store into a slab
+    if (p.partial != nullptr && p.splits > 1) {
+        dst = p.partial + (size_t)blockIdx.z * p.partial_stride;
+        how = 2;
+    } else if (p.splits <= 1) {
+        how = 1;
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float* row = p.dw + (size_t)(co0 + wco * 64 + a * 16 + lg * 4 + j) * p.Kw + colb + l15;
+            float* row = dst + (size_t)(co0 + wco * 64 + a * 16 + lg * 4 + j) * p.Kw + colb + l15;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) atomicAdd(row + b * 16, acc[a][b][j]);
+            for (int b = 0; b < 4; ++b) {
+                if (how == 0) atomicAdd(row + b * 16, acc[a][b][j]);
+                else if (how == 1) row[b * 16] += acc[a][b][j];
+                else row[b * 16] = acc[a][b][j];
+            }
         }
 }
 
@@ -237,6 +248,24 @@ int launch_wgrad(const VcWgradParams& p, int splits, hipStream_t stream) {
 
 }  // namespace
 
+int vc_wgrad_splits(int M, int Co, int nblk, int* rows_per_split) {
+    const bool wide = (Co % 128 == 0);
+    const int nb = wide ? 2 : 4;
+    const int bco = wide ? 128 : 64;
+    const long tiles = (long)((nblk + nb - 1) / nb) * (Co / bco);
+    // aim for ~1024 workgroups, at least 4 chunks (256 rows) per split
+    long splits = (1024 + tiles - 1) / tiles;
+    const long maxsplits = (M + 255) / 256;
+    if (splits > maxsplits) splits = maxsplits;
+    if (splits < 1) splits = 1;
+    if (splits > 1024) splits = 1024;
+    long rps = (M + splits - 1) / splits;
+    rps = (rps + 63) / 64 * 64;
+    splits = (M + rps - 1) / rps;
+    *rows_per_split = (int)rps;
+    return (int)splits;
+}
+
 int vc_launch_wgrad(const VcWgradParams& p_in, int mode, hipStream_t stream) {
     VcWgradParams p = p_in;
     if (p.M <= 0) return 0;
@@ -245,21 +274,12 @@ int vc_launch_wgrad(const VcWgradParams& p_in, int mode, hipStream_t stream) {
         return -2;
     }
     const bool wide = (p.Co % 128 == 0);
-    const int nb = wide ? 2 : 4;
-    const int bco = wide ? 128 : 64;
     const int nblk = (mode == 0) ? p.ntaps * (p.Cs / 64) : p.Kw / 64;
-    const long tiles = (long)((nblk + nb - 1) / nb) * (p.Co / bco);
-    // aim for ~1024 workgroups, at least 4 chunks (256 rows) per split
-    long splits = (1024 + tiles - 1) / tiles;
-    const long maxsplits = (p.M + 255) / 256;
-    if (splits > maxsplits) splits = maxsplits;
-    if (splits < 1) splits = 1;
-    if (splits > 65535) splits = 65535;
-    long rps = (p.M + splits - 1) / splits;
-    rps = (rps + 63) / 64 * 64;
-    splits = (p.M + rps - 1) / rps;
-    p.rows_per_split = (int)rps;
-    if (mode == 1) return launch_wgrad<64, 4, 1>(p, (int)splits, stream);
-    if (wide) return launch_wgrad<128, 2, 0>(p, (int)splits, stream);
-    return launch_wgrad<64, 4, 0>(p, (int)splits, stream);
+    int rps = 0;
+    const int splits = vc_wgrad_splits(p.M, p.Co, nblk, &rps);
+    p.rows_per_split = rps;
+    p.splits = splits;
+    if (mode == 1) return launch_wgrad<64, 4, 1>(p, splits, stream);
+    if (wide) return launch_wgrad<128, 2, 0>(p, splits, stream);
+    return launch_wgrad<64, 4, 0>(p, splits, stream);
 }

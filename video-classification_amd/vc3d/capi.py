@@ -56,9 +56,10 @@ PROTOTYPES = {
     "vc_last_error": [],
     "vc_abi_version": [],
     "vc_conv3d_out_dims": [_CD, _IP, _IP, _IP],
-    "vc_conv3d_fwd": [_CD, _P, _P, _P, _P, _P],
-    "vc_conv3d_dgrad": [_CD, _P, _P, _P, _I, _P],
-    "vc_conv3d_wgrad": [_CD, _P, _P, _P, _P],
+    "vc_conv3d_workspace_bytes": [_CD, _I],
+    "vc_conv3d_fwd": [_CD, _P, _P, _P, _P, _P, C.c_size_t, _P],
+    "vc_conv3d_dgrad": [_CD, _P, _P, _P, _I, _P, C.c_size_t, _P],
+    "vc_conv3d_wgrad": [_CD, _P, _P, _P, _P, C.c_size_t, _P],
     "vc_pack_weight": [_P, _P, _P, _I, _I, _I, _P],
     "vc_stem_packed_input_elems": [_I, _I, _I, _I],
     "vc_stem_pack_input": [_P, _I, _P, _I, _I, _I, _I, _P],
@@ -84,7 +85,8 @@ PROTOTYPES = {
     "vc_ncthw_to_nthwc": [_P, _I, _P, _I, _I, _L, _P],
     "vc_nthwc_to_ncthw": [_P, _P, _I, _I, _I, _L, _P],
 }
-_RESTYPE = {"vc_last_error": C.c_char_p, "vc_stem_packed_input_elems": C.c_size_t}
+_RESTYPE = {"vc_last_error": C.c_char_p, "vc_stem_packed_input_elems": C.c_size_t,
+            "vc_conv3d_workspace_bytes": C.c_size_t}
 
 
 def _load():

@@ -64,6 +64,25 @@ def _chk(t, dtype, numel=None, name="tensor"):
         raise capi.Vc3dError("%s: expected %d elements, got %d" % (name, numel, t.numel()))
 
 
+_WS = {}  # device -> split-K workspace (grown on demand; reuse is safe: launches are stream-ordered)
+USE_WORKSPACE = True
+
+
+def _workspace(d, op, device):
+    """(ptr, bytes) of a workspace large enough for conv `d`, op 0/1/2; (None, 0) if none is needed."""
+    if not USE_WORKSPACE:
+        return None, 0
+    need = int(lib.vc_conv3d_workspace_bytes(d, op))
+    if need == 0:
+        return None, 0
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf.data_ptr(), buf.numel()
+
+
 def conv_desc(N, Ci, T, H, W, Co, k, s, p):
     k = (k,) * 3 if isinstance(k, int) else tuple(k)
     s = (s,) * 3 if isinstance(s, int) else tuple(s)
@@ -98,7 +117,8 @@ def conv3d_fwd(d, x, wf, stats=None, out=None):
     _chk(out, BF16, d.N * To * Ho * Wo * d.Co, "y")
     _chk(stats, F32, VC_STAT_REPLICAS * 2 * d.Co, "bn_stats")
     ev = TIMER.begin(_conv_key("fwd", d), _conv_flops(d)) if TIMER is not None else None
-    check(lib.vc_conv3d_fwd(d, ptr(x), ptr(wf), ptr(out), ptr(stats), cur_stream()), "vc_conv3d_fwd")
+    ws, wsb = _workspace(d, 0, x.device)
+    check(lib.vc_conv3d_fwd(d, ptr(x), ptr(wf), ptr(out), ptr(stats), ws, wsb, cur_stream()), "vc_conv3d_fwd")
     if ev is not None:
         ev.record()
     return out
@@ -115,7 +135,9 @@ def conv3d_dgrad(d, dy, wd, out=None, accumulate=False):
         out = torch.empty(d.N, d.Ti, d.Hi, d.Wi, d.Ci, dtype=BF16, device=dy.device)
     _chk(out, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "dx")
     ev = TIMER.begin(_conv_key("dgrad", d), _conv_flops(d)) if TIMER is not None else None
-    check(lib.vc_conv3d_dgrad(d, ptr(dy), ptr(wd), ptr(out), 1 if accumulate else 0, cur_stream()), "vc_conv3d_dgrad")
+    ws, wsb = _workspace(d, 1, dy.device)
+    check(lib.vc_conv3d_dgrad(d, ptr(dy), ptr(wd), ptr(out), 1 if accumulate else 0, ws, wsb, cur_stream()),
+          "vc_conv3d_dgrad")
     if ev is not None:
         ev.record()
     return out
@@ -129,7 +151,8 @@ def conv3d_wgrad(d, x, dy, dw):
     _chk(dy, BF16, d.N * To * Ho * Wo * d.Co, "dy")
     _chk(dw, F32, d.Co * taps * d.Ci, "dw")
     ev = TIMER.begin(_conv_key("wgrad", d), _conv_flops(d)) if TIMER is not None else None
-    check(lib.vc_conv3d_wgrad(d, ptr(x), ptr(dy), ptr(dw), cur_stream()), "vc_conv3d_wgrad")
+    ws, wsb = _workspace(d, 2, x.device)
+    check(lib.vc_conv3d_wgrad(d, ptr(x), ptr(dy), ptr(dw), ws, wsb, cur_stream()), "vc_conv3d_wgrad")
     if ev is not None:
         ev.record()
     return dw
