@@ -25,37 +25,43 @@ namespace {
 constexpr int BK = 64;           // K elements per chunk
 constexpr int ROWB = BK * 2;     // bytes per LDS tile row
 
+// masked (out-of-bounds) lanes of an LDS-DMA load fetch zeros from here
+__device__ __attribute__((aligned(128))) unsigned int vc_zero_page[32];
+
 template <int BCO, int BM>
 struct IgemmCfg {
     static constexpr int WCO = BCO / 64;           // waves along co
     static constexpr int WM = BM / 64;             // waves along m
-    static constexpr int NX = BM / 32;             // 16-B X loads per thread per chunk
-    static constexpr int NW = BCO / 32;            // 16-B W loads per thread per chunk
-    static constexpr int LDS_BYTES = (BCO + BM) * ROWB + BM * 12;
+    static constexpr int NX = BM / 32;             // 1-KiB X pieces per wave per chunk
+    static constexpr int NW = BCO / 32;            // 1-KiB W pieces per wave per chunk
+    static constexpr int BUF_BYTES = (BCO + BM) * ROWB;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;  // double buffered; the prologue's row table lives in buffer 1
     static_assert(WCO * WM == 4, "4 waves per workgroup");
+    static_assert(BM * 12 <= BUF_BYTES, "row table must fit in one buffer");
 };
 
-__device__ __forceinline__ int swz_off(int row, int slot) {
-    return row * ROWB + ((slot ^ ((row >> 1) & 7)) << 4);
-}
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Data path: global --(LDS-DMA, 16 B per lane, 1 KiB per wave instruction)--> LDS --> ds_read_b128
+// fragments --> MFMA.  An LDS-DMA piece lands lane-linear (8 rows x 128 B), so the XOR swizzle that
+// keeps the fragment reads conflict-free is applied to the SOURCE address: the lane that fills
+// 16-B slot p of row r fetches logical slot p ^ ((r >> 1) & 7).
 template <int BCO, int BM, int MODE>  // MODE 0: tap table with bounds masks; 1: stem (padded s2d source)
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
     using Cfg = IgemmCfg<BCO, BM>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sW = smem;
-    char* sX = smem + BCO * ROWB;
-    int* sRowBase = (int*)(sX + BM * ROWB);
-    unsigned* sRowMask = (unsigned*)(sRowBase + BM);
-    int* sOutOff = (int*)(sRowMask + BM);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * BM;
     const int co0 = blockIdx.y * BCO;
 
-    // ---- per-row geometry, one row per thread, shared through LDS ----
+    // ---- per-row geometry, one row per thread, staged in buffer 1 (unused until the first prefetch)
+    int* sRowBase = (int*)(smem + Cfg::BUF_BYTES);
+    unsigned* sRowMask = (unsigned*)(sRowBase + BM);
+    int* sOutOff = (int*)(sRowMask + BM);
     for (int r = tid; r < BM; r += 256) {
         const int m = m0 + r;
         int base = 0, ooff = -1;
@@ -87,9 +93,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
     }
     __syncthreads();
 
-    // ---- loader state ----
-    const int lrow = tid >> 3;  // 0..31
-    const int lslot = tid & 7;  // 16-B slot inside the 128-B chunk row
+    // ---- loader state: this lane fills LDS position (row = piece*32 + lrow, physical slot lane&7)
+    const int lrow = tid >> 3;                    // 0..31 = wave*8 + (lane>>3)
+    const int lslot = (tid & 7) ^ ((lrow >> 1) & 7);  // logical (source) slot fetched by this lane
     int rb[Cfg::NX];
     unsigned rm[Cfg::NX];
 #pragma unroll
@@ -101,58 +107,46 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
 #pragma unroll
     for (int j = 0; j < Cfg::NW; ++j) wb[j] = (co0 + j * 32 + lrow) * p.Kw + lslot * 8;
 
-    bf16x8 xr[Cfg::NX];
-    bf16x8 wr[Cfg::NW];
-
-    const int cpt = (MODE == 0) ? (p.Cs >> 6) : 1;               // chunks per tap
-    const int nchunks = (MODE == 0) ? p.ntaps * cpt : (p.Kw >> 6);
-
-    auto load_chunk = [&](int ti, int c0, int chunk) {
-        if (MODE == 0) {
-            const int soff = p.taps[ti].src_off + c0;
-            const int woff = p.taps[ti].wk_off + c0;
-#pragma unroll
-            for (int i = 0; i < Cfg::NX; ++i) {
-                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if ((rm[i] >> ti) & 1u) v = *(const bf16x8*)(p.src + (rb[i] + soff));
-                xr[i] = v;
-            }
-#pragma unroll
-            for (int j = 0; j < Cfg::NW; ++j) wr[j] = *(const bf16x8*)(p.wgt + (wb[j] + woff));
-        } else {
-            // stem: K = 28 macro-taps (kt, a_h) x 48 contiguous elements (a_w, b_h, b_w, c)
-            const int g = chunk * 8 + lslot;  // 8-element K group
-            const int j = g / 6;
-            const int within = (g - j * 6) * 8;
-            const int kt = j >> 2, ahh = j & 3;
-            const int soff = ((kt * p.Hs + ahh) * p.Ws) * p.Cs + within;
-#pragma unroll
-            for (int i = 0; i < Cfg::NX; ++i) {
-                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (rm[i]) {
-                    const bf16x4* q = (const bf16x4*)(p.src + (rb[i] + soff));  // 8-B aligned only
-                    bf16x4 lo = q[0], hi = q[1];
-                    v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-                xr[i] = v;
-            }
-#pragma unroll
-            for (int jj = 0; jj < Cfg::NW; ++jj) wr[jj] = *(const bf16x8*)(p.wgt + (wb[jj] + chunk * 64));
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < Cfg::NX; ++i) *(bf16x8*)(sX + swz_off(i * 32 + lrow, lslot)) = xr[i];
-#pragma unroll
-        for (int j = 0; j < Cfg::NW; ++j) *(bf16x8*)(sW + swz_off(j * 32 + lrow, lslot)) = wr[j];
-    };
-
-    // ---- MFMA state ----
+    // ---- MFMA / epilogue lane roles
     const int wco = wave % Cfg::WCO;
     const int wm = wave / Cfg::WCO;
     const int l15 = lane & 15;
     const int lg = lane >> 4;
     const int lswz = (lane >> 1) & 7;  // == ((row >> 1) & 7) for row = 16*x + l15
+    int ooff[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) ooff[b] = sOutOff[wm * 64 + b * 16 + l15];
+    __syncthreads();  // the row table has been consumed; buffer 1 may be overwritten
+
+    const int cpt = (MODE == 0) ? (p.Cs >> 6) : 1;               // chunks per tap
+    const int nchunks = (MODE == 0) ? p.ntaps * cpt : (p.Kw >> 6);
+    const gptr_t zero = (gptr_t)vc_zero_page;
+
+    auto issue_chunk = [&](int ti, int c0, int chunk, int buf) {
+        char* bW = smem + buf * Cfg::BUF_BYTES + wave * (8 * ROWB);
+        char* bX = bW + BCO * ROWB;
+        int soff, woff;
+        if (MODE == 0) {
+            soff = p.taps[ti].src_off + c0;
+            woff = p.taps[ti].wk_off + c0;
+        } else {
+            // stem: K = 28 macro-taps (kt, a_h) x 48 contiguous elements (a_w, b_h, b_w, c)
+            const int g = chunk * 8 + lslot;  // 8-element K group fetched by this lane
+            const int j = g / 6;
+            soff = (((j >> 2) * p.Hs + (j & 3)) * p.Ws) * p.Cs + (g - j * 6) * 8;
+            woff = chunk * 64;
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::NW; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.wgt + (wb[j] + woff)), (lptr_t)(bW + j * 32 * ROWB), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < Cfg::NX; ++i) {
+            const bool ok = (MODE == 0) ? (((rm[i] >> ti) & 1u) != 0) : (rm[i] != 0);
+            const gptr_t src = ok ? (gptr_t)(p.src + (rb[i] + soff)) : zero;
+            __builtin_amdgcn_global_load_lds(src, (lptr_t)(bX + i * 32 * ROWB), 16, 0, 0);
+        }
+    };
+
     f32x4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -169,21 +163,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
         ti = cbeg / cpt;
         c0 = (cbeg - ti * cpt) * 64;
     }
-    if (cbeg < cend) {
-        load_chunk(ti, c0, cbeg);
-        store_chunk();
-    }
-    __syncthreads();
+    if (cbeg < cend) issue_chunk(ti, c0, cbeg, 0);
 
+    int buf = 0;
     for (int c = cbeg; c < cend; ++c) {
+        // chunk c has landed for every wave (the barrier drains this wave's LDS-DMA first), and every
+        // wave is done reading the other buffer (it was read one iteration ago)
+        __syncthreads();
         int nti = ti, nc0 = c0 + 64;
         if (MODE == 0 && nc0 >= p.Cs) {
             nc0 = 0;
             nti = ti + 1;
         }
-        const bool more = (c + 1 < cend);
-        if (more) load_chunk(nti, nc0, c + 1);
+        if (c + 1 < cend) issue_chunk(nti, nc0, c + 1, buf ^ 1);
 
+        const char* sW = smem + buf * Cfg::BUF_BYTES;
+        const char* sX = sW + BCO * ROWB;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
@@ -200,20 +195,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
                 for (int b = 0; b < 4; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
-        __syncthreads();
-        if (more) {
-            store_chunk();
-            __syncthreads();
-        }
         ti = nti;
         c0 = nc0;
+        buf ^= 1;
     }
 
     // ---- epilogue ----
     // acc[a][b][j] = D[co = co0 + wco*64 + a*16 + lg*4 + j][m = m0 + wm*64 + b*16 + l15]
-    int ooff[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) ooff[b] = sOutOff[wm * 64 + b * 16 + l15];
     const int cobase = co0 + wco * 64 + lg * 4;
 
     if (p.partial != nullptr) {
@@ -300,7 +288,7 @@ int vc_igemm_splits(int M, int Cn, int nchunks) {
     const long wgs = (long)((M + (wide ? 127 : 255)) / (wide ? 128 : 256)) * (Cn / (wide ? 128 : 64));
     if (wgs >= 384 || nchunks < 8) return 1;
     long s = (768 + wgs - 1) / wgs;
-    if (s > nchunks / 4) s = nchunks / 4;
+    if (s > nchunks / 16) s = nchunks / 16;  // slabs cost output-sized traffic: only split long K loops
     if (s > 32) s = 32;
     return s < 2 ? 1 : (int)s;
 }
