@@ -1,0 +1,265 @@
+"""CPU tests of the drop-in boundary and the host logic (no GPU, no compute launches).
+
+ - libvc3d.so loads and exports every symbol include/vc3d.h declares; shape logic that runs
+   on the host (output dims, workspace sizes, argument validation) answers without a GPU;
+ - the reference's Python surface is mirrored: config keys, create_model / getBackbone /
+   BackBone attribute names and state_dict keys, Loss, create_optimizer, AverageMeter,
+   init_weights behaviour (reference file:line in each test);
+ - the product path refuses CPU tensors loudly (there is no fallback);
+ - data-parallel gradient bucketing: 2 ranks over gloo.
+"""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import torch.nn as nn
+
+from helpers import make_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C ABI
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vc3d.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vc3d import capi
+    syms = _declared_symbols()
+    assert len(syms) >= 30
+    raw = ctypes.CDLL(capi.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), "libvc3d.so does not export %s" % s
+    assert set(capi.PROTOTYPES) == set(syms), "ctypes binding and header disagree: %s" % (
+        set(capi.PROTOTYPES) ^ set(syms))
+    assert capi.lib.vc_abi_version() == 1
+
+
+def test_host_side_shape_logic():
+    from vc3d import capi, ops
+    d = ops.conv_desc(64, 64, 8, 28, 28, 128, 3, 2, 1)
+    to, ho, wo = (ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32())
+    assert capi.lib.vc_conv3d_out_dims(d, to, ho, wo) == 0
+    assert (to.value, ho.value, wo.value) == (4, 14, 14) == d.out_dims()
+    # same arithmetic as torch's Conv3d for every (k, s, p) of the layer table
+    for (T, H, W, k, s, p) in [(16, 56, 56, 3, 1, 1), (1, 7, 7, 3, 2, 1), (8, 28, 28, 1, 2, 0), (5, 9, 7, 3, 2, 1)]:
+        dd = ops.conv_desc(1, 64, T, H, W, 64, k, s, p)
+        want = tuple(nn.Conv3d(1, 1, k, s, p)(torch.zeros(1, 1, T, H, W)).shape[2:])
+        assert dd.out_dims() == want
+    pd = ops.pool_desc(2, 64, 16, 56, 56)
+    assert capi.lib.vc_pool3d_out_dims(pd, to, ho, wo) == 0
+    assert (to.value, ho.value, wo.value) == (8, 28, 28)
+    assert capi.lib.vc_stem_packed_input_elems(2, 16, 112, 112) == 2 * 22 * 59 * 59 * 12
+    # workspace query is pure host arithmetic; a big grid needs none
+    assert capi.lib.vc_conv3d_workspace_bytes(ops.conv_desc(64, 64, 8, 28, 28, 64, 3, 1, 1), 0) == 0
+
+
+def test_bad_descriptors_are_rejected_on_the_host():
+    from vc3d import capi, ops
+    to, ho, wo = (ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32())
+    bad = ops.conv_desc(1, 64, 2, 2, 2, 64, 7, 1, 0)  # kernel larger than the padded input
+    assert capi.lib.vc_conv3d_out_dims(bad, to, ho, wo) != 0
+    assert b"conv3d" in capi.lib.vc_last_error()
+    # channel counts the MFMA tiling cannot take: rejected before any launch
+    d = ops.conv_desc(1, 48, 2, 4, 4, 64, 3, 1, 1)
+    rc = capi.lib.vc_conv3d_fwd(d, None, None, None, None, None, 0, None)
+    assert rc != 0 and b"multiples of 64" in capi.lib.vc_last_error()
+    d = ops.conv_desc(1, 64, 2, 4, 4, 64, 3, 1, 1)
+    rc = capi.lib.vc_conv3d_fwd(d, None, None, None, None, None, 0, None)
+    assert rc != 0 and b"null pointer" in capi.lib.vc_last_error()
+    with pytest.raises(capi.Vc3dError):
+        capi.check(rc, "vc_conv3d_fwd")
+
+
+def test_no_cpu_fallback():
+    """a CPU tensor must raise, not silently run somewhere else."""
+    from vc3d.capi import Vc3dError
+    from models.model import create_model
+    model = create_model(make_config(18, 11), is_train=True)
+    with pytest.raises(Vc3dError, match="no CPU fallback|GPU only"):
+        model(torch.zeros(1, 3, 4, 16, 16))
+    from vc3d import ops
+    with pytest.raises(Vc3dError):
+        ops.bn_apply(torch.zeros(1, 1, 1, 1, 64, dtype=torch.bfloat16), torch.zeros(4, 64), 64)
+
+
+# ------------------------------------------------------------------ reference API mirror
+def test_config_keys_match_reference():
+    """reference lib/core/config.py:12-69 (key names and defaults)."""
+    from core.config import config
+    assert (config.GPUS, config.WORKERS, config.DATASET, config.OUTPUT_DIR) == ('0', 0, 'FCVID', 'experiments')
+    assert config.MODEL.LSTM_INDIM == 2048 and config.MODEL.LSTM_OUTDIM == 2048 and config.MODEL.CLFDIM == 100
+    assert config.MODEL.RESNET_TYPE == 18 and config.MODEL.INIT_WEIGHTS is True
+    t = config.TRAIN
+    assert (t.LR, t.LR_DECAY_RATE, t.LR_MILESTONES, t.OPTIMIZER, t.MOMENTUM, t.WD, t.NESTEROV) == (
+        0.001, 1, [], 'adam', 0.9, 0.0001, False)
+    assert (t.R_ACT, t.R_CRT, t.TRAIN_STEP, t.ROLLOUT_STEP, t.BEGIN_EPOCH, t.END_EPOCH, t.BATCH_SIZE, t.SHUFFLE,
+            t.PRINT_EVERY) == (1, 1, 10, 1, 0, 100, 32, True, 100)
+    assert (config.TEST.TEST_STEP, config.TEST.BATCH_SIZE, config.TEST.PRINT_EVERY) == (10, 32, 100)
+    c2 = config.clone()
+    c2.TRAIN.LR = 1.0
+    assert config.TRAIN.LR == 0.001
+
+
+@pytest.mark.parametrize("depth,convs,feat", [(18, 20, 512), (50, 53, 2048)])
+def test_backbone_names_and_counts(depth, convs, feat):
+    """attribute names = checkpoint keys (reference backbone.py:108-125), conv/BN counts of the 2D
+    reference, state_dict key set identical to the oracle's."""
+    from models.backbone import getBackbone, resnet_spec, BackBone
+    from oracle.r3d_torch import BackBone3D, resnet_spec as ospec
+    cfg = make_config(depth, 101)
+    bb = getBackbone(cfg, is_train=True)
+    assert isinstance(bb, BackBone) and bb.out_features == feat
+    for name in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4", "final_layer"):
+        assert hasattr(bb, name)
+    assert sum(isinstance(m, nn.Conv3d) for m in bb.modules()) == convs
+    assert sum(isinstance(m, nn.BatchNorm3d) for m in bb.modules()) == convs
+    assert all(m.momentum == 0.1 for m in bb.modules() if isinstance(m, nn.BatchNorm3d))  # backbone.py:13
+    assert all(m.bias is None for m in bb.modules() if isinstance(m, nn.Conv3d))
+    ob = BackBone3D(*ospec[depth])
+    assert set(bb.state_dict()) == set(ob.state_dict())
+    assert {k: tuple(v.shape) for k, v in bb.state_dict().items()} == {k: tuple(v.shape) for k, v in
+                                                                        ob.state_dict().items()}
+    assert sorted(resnet_spec) == [18, 34, 50, 101, 152]  # backbone.py:188-192
+    # Bottleneck carries the stride on the 3x3 (backbone.py:72)
+    if depth == 50:
+        blk = bb.layer2[0]
+        assert blk.conv1.stride == (1, 1, 1) and blk.conv2.stride == (2, 2, 2)
+
+
+def test_create_model_returns_reference_triple_shape_contract():
+    from models.model import create_model, VedioClfNet
+    m = create_model(make_config(18, 101), is_train=True)
+    assert isinstance(m, VedioClfNet)
+    assert isinstance(m.clf_haed, nn.Linear) and m.clf_haed.in_features == 512 and m.clf_haed.out_features == 101
+
+
+def test_init_weights_reference_behaviour(tmp_path):
+    """backbone.py:159-185: missing file -> ValueError; {'state_dict': ...} accepted; 'module.'
+    prefix stripped; strict=False; 2D kernels are inflated along T (repeat / kT)."""
+    from models.backbone import getBackbone
+    cfg = make_config(18, 101)
+    cfg.MODEL.INIT_WEIGHTS = True
+    cfg.MODEL.PRETRAINED_PATH = str(tmp_path / "nope.pth")
+    with pytest.raises(ValueError):
+        getBackbone(cfg, is_train=True)
+    getBackbone(cfg, is_train=False)  # not loaded when is_train is False (backbone.py:210)
+    bb = getBackbone(make_config(18, 101), True)
+    w2d = torch.randn(64, 64, 3, 3)
+    sd = {"module.layer1.0.conv1.weight": w2d, "module.bn1.weight": torch.full((64,), 2.0), "unknown.key": torch.ones(1)}
+    path = str(tmp_path / "ck.pth")
+    torch.save({"state_dict": sd}, path)
+    bb.init_weights(path)
+    w = bb.layer1[0].conv1.weight
+    assert torch.allclose(w.sum(2), w2d, atol=1e-6) and torch.allclose(w[:, :, 0], w2d / 3)
+    assert float(bb.bn1.weight[0]) == 2.0
+    assert w.is_contiguous(memory_format=torch.channels_last_3d)
+
+
+def test_optimizer_meter_logger(tmp_path):
+    """reference utils.py:13-36 (create_optimizer), :39-54 (AverageMeter), :84-104 (create_logger)."""
+    from utils.utils import create_optimizer, AverageMeter, create_logger, ChooseInput, rollout
+    model = nn.Linear(4, 2)
+    cfg = make_config(18, 10, OPTIMIZER="sgd", NESTEROV=True)
+    opt = create_optimizer(cfg, model)
+    g = opt.param_groups[0]
+    assert isinstance(opt, torch.optim.SGD) and (g["lr"], g["momentum"], g["weight_decay"], g["nesterov"]) == (
+        0.001, 0.9, 0.0001, True)
+    cfg.TRAIN.OPTIMIZER = "adam"
+    assert isinstance(create_optimizer(cfg, model), torch.optim.Adam)
+    cfg.TRAIN.OPTIMIZER = "lamb"
+    assert create_optimizer(cfg, model) is None  # utils.py:21,36
+    m = AverageMeter()
+    assert m.avg == 0 and m.count == 0
+    m.update(2.0, 3)
+    m.update(4.0, 1)
+    assert (m.val, m.sum, m.count, m.avg) == (4.0, 10.0, 4, 2.5)
+    cfg.OUTPUT_DIR = str(tmp_path / "out")
+    lg = create_logger(cfg, "train")
+    lg.info("hello")
+    files = os.listdir(cfg.OUTPUT_DIR)
+    assert len(files) == 1 and files[0].startswith("FCVID_") and files[0].endswith("_train.log")
+    for h in list(lg.handlers):
+        lg.removeHandler(h)
+    v = torch.zeros(1)
+    assert ChooseInput(v, None) is v and rollout(v, None, None, None) == (None, None)
+
+
+def test_synthetic_dataset_shapes():
+    from dataset.dataset import get_dataset
+    cfg = make_config(18, 7)
+    cfg.MODEL.CLIP_LEN, cfg.MODEL.CROP_SIZE = 4, 16
+    ds = get_dataset(True, cfg, length=3)
+    x, y = ds[1]
+    assert len(ds) == 3 and tuple(x.shape) == (3, 4, 16, 16) and 0 <= y < 7
+    x2, y2 = ds[1]
+    assert torch.equal(x, x2) and y == y2
+
+
+# ------------------------------------------------------------------ data parallel (gloo, 2 ranks)
+def _ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vc3d.ddp import GradBucketReducer, broadcast_module
+        torch.manual_seed(100 + rank)
+        mod = nn.Sequential(nn.Linear(5, 3), nn.BatchNorm1d(3))
+        broadcast_module(mod, 0)
+        w0 = mod[0].weight.detach().clone()
+        sizes = [7, 130, 5, 64, 9]  # several parameters per bucket, one bucket boundary inside
+        flat = torch.zeros(sum(sizes))
+        ranges, off = [], 0
+        for i, n in enumerate(sizes):
+            ranges.append((i, off, n))
+            off += n
+        red = GradBucketReducer(flat, ranges, bucket_bytes=4 * 140)
+        nb = len(red.buckets)
+        for step in range(2):  # the reducer is reused across steps
+            flat.copy_(torch.arange(flat.numel(), dtype=torch.float32) * (rank + 1) + step)
+            for i in range(len(sizes) - 1):  # the last parameter never reports (unused): finish() flushes it
+                red.on_ready(i)
+            red.finish()
+            want = torch.arange(flat.numel(), dtype=torch.float32) * (sum(range(1, world + 1)) / world) + step
+            assert torch.allclose(flat, want), (rank, step)
+        gathered = [torch.zeros_like(w0) for _ in range(world)]
+        dist.all_gather(gathered, w0)
+        assert all(torch.equal(gathered[0], t) for t in gathered)
+        out.put((rank, nb))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_bucket_reducer_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = sorted(q.get() for _ in range(2))
+    assert [r for r, _ in res] == [0, 1] and res[0][1] >= 2
+
+
+def test_bucket_layout_single_process():
+    from vc3d.ddp import GradBucketReducer
+    flat = torch.zeros(100)
+    red = GradBucketReducer(flat, [("a", 0, 30), ("b", 30, 30), ("c", 60, 40)], bucket_bytes=4 * 50)
+    assert [b[:2] for b in red.buckets] == [[0, 60], [60, 100]]
+    assert red.key2bucket == {"a": 0, "b": 0, "c": 1}
+    red.on_ready("a")
+    assert red.launched == [False, False]
+    red.on_ready("b")
+    assert red.launched == [True, False]
+    red.finish()
+    assert red.launched == [False, False]  # reset for the next step
