@@ -22,7 +22,7 @@ What it writes, and what pins what:
       torch 2.10.0 CPU): conv3d fwd/dgrad/wgrad for every (kernel, stride, pad) of the layer
       table, train-mode BatchNorm3d fwd/bwd with running statistics, MaxPool3d fwd/bwd,
       global average pool, Linear.  Inputs are stored with the outputs.
-  r3d18_small.npz                 -- whole-net oracle R3D-18 on a seeded 2x3x8x32x32 batch:
+  r3d18_small.npz                 -- whole-net oracle R3D-18 on a seeded 4x3x8x64x64 batch (2 clips of 32x32 leave late BN layers with 2 values per channel: ill-conditioned):
       logits, loss, per-parameter gradient norms, BN running statistics after one step.
 
 Inputs and weights that are too large to commit are regenerated from seeds; a SHA-256 of
@@ -189,7 +189,7 @@ def ops3d():
 
 def r3d18_small():
     model = init_weights_(R3DOracle(18, 101), 0).train()
-    x, y = synthetic_batch(2, 8, 32, 32, 101, 4321)
+    x, y = synthetic_batch(4, 8, 64, 64, 101, 4321)
     wsha = hashlib.sha256(b"".join(p.detach().numpy().tobytes() for p in model.parameters())).hexdigest()
     logits = model(x)
     loss = F.cross_entropy(logits, y)

@@ -126,7 +126,7 @@ def test_r3d18_small_fixture_is_reproduced_by_this_torch():
     model = init_weights_(R3DOracle(18, 101), 0).train()
     if params_sha(list(model.parameters())) != g["w_sha"]:
         pytest.skip("torch RNG stream differs from the one the fixture was generated with")
-    x, y = synthetic_batch(2, 8, 32, 32, 101, 4321)
+    x, y = synthetic_batch(4, 8, 64, 64, 101, 4321)
     assert params_sha([x]) == g["x_sha"]
     logits = model(x)
     loss = F.cross_entropy(logits, y)
