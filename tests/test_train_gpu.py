@@ -1,0 +1,82 @@
+"""GPU tests of the entry points: train.py / valid.py flows (reference train.py:29-91,
+valid.py:28-61) and the reference-style step loop (function.py:58-85) on the HIP path."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import make_config
+
+pytestmark = pytest.mark.gpu
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-classification_amd")
+
+
+def test_loss_decreases_on_a_fixed_batch():
+    """forward + backward + SGD through the product path must fit one batch: the gradient signs and
+    the optimizer wiring (flat gradient views as param.grad) are right."""
+    from models.model import create_model
+    from core.loss import Loss
+    from utils.utils import create_optimizer
+    torch.manual_seed(0)
+    cfg = make_config(18, 8, OPTIMIZER="sgd", LR=0.05)
+    model = create_model(cfg, True).cuda().train()
+    crit = Loss(cfg)
+    opt = create_optimizer(cfg, model)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 3, 4, 32, 32, generator=g).cuda()
+    y = torch.randint(0, 8, (8,), generator=g).cuda()
+    losses = []
+    for _ in range(12):
+        _, score, _ = model(x)
+        loss = crit(score, y, None, None)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    print("losses", ["%.3f" % v for v in losses])
+    assert losses[-1] < 0.5 * losses[0]
+
+
+def test_train_and_valid_entry_points(tmp_path, monkeypatch):
+    monkeypatch.syspath_prepend(PKG)
+    monkeypatch.chdir(tmp_path)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    import train as train_mod
+    import valid as valid_mod
+    common = ["MODEL.INIT_WEIGHTS=false", "MODEL.CLFDIM=5", "MODEL.CLIP_LEN=4", "MODEL.CROP_SIZE=32",
+              "OUTPUT_DIR=%s" % (tmp_path / "exp"), "TRAIN.PRINT_EVERY=1", "TEST.PRINT_EVERY=1"]
+    best = train_mod.main(common + ["TRAIN.END_EPOCH=1", "TRAIN.BATCH_SIZE=4", "TEST.BATCH_SIZE=4", "TRAIN.TRAIN_STEP=2",
+                                    "TRAIN.OPTIMIZER=sgd"])
+    assert 0.0 <= best <= 1.0
+    ck = tmp_path / "exp" / "model_best.pth"
+    assert ck.is_file()
+    acc = valid_mod.main(common + ["TEST.BATCH_SIZE=6", "TEST.NUM_CLIPS=2", "TEST.NUM_CROPS=3", "CKPT=%s" % ck])
+    assert 0.0 <= acc <= 1.0
+    import logging
+    for h in list(logging.getLogger().handlers):
+        logging.getLogger().removeHandler(h)
+
+
+def test_multi_view_validation_averages_logits():
+    """validate() on N x V views == argmax of the mean of the V per-view logits."""
+    from models.model import create_model
+    from core.function import validate
+    from core.loss import Loss
+    cfg = make_config(18, 6)
+    cfg.TEST.BATCH_SIZE = 4
+    cfg.TEST.PRINT_EVERY = 100
+    torch.manual_seed(1)
+    model = create_model(cfg, False).cuda()
+    g = torch.Generator().manual_seed(5)
+    vids = torch.randn(3, 5, 3, 4, 32, 32, generator=g)
+    model.eval()
+    with torch.no_grad():
+        lo = torch.stack([model(vids[i].cuda())[1] for i in range(3)])  # 3 x 5 x classes
+    pred = lo.mean(1).argmax(1).cpu()
+    acc = validate(cfg, [(vids, pred.clone())], model, Loss(cfg), 0)
+    assert acc == 1.0
+    wrong = (pred + 1) % 6
+    assert validate(cfg, [(vids, wrong)], model, Loss(cfg), 0) == 0.0

@@ -23,3 +23,18 @@ def get_dataset(if_train=True, config=None, length=None):
     n = length if length is not None else (256 if if_train else 64)
     return SyntheticClips(n, cfg.MODEL.CLIP_LEN, cfg.MODEL.CROP_SIZE, cfg.MODEL.CLFDIM,
                           seed=1234 if if_train else 4321)
+
+
+class MultiViewClips(Dataset):
+    """validation videos as V views (clips x crops) each: item = (V x 3 x T x H x W, label)."""
+
+    def __init__(self, length, views, clip_len=16, crop=112, classes=100, seed=4321):
+        self.length, self.views, self.shape, self.classes, self.seed = length, views, (3, clip_len, crop, crop), classes, seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        return (torch.randn((self.views,) + self.shape, generator=g),
+                int(torch.randint(0, self.classes, (1,), generator=g)))

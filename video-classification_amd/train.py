@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Training entry point with the reference's flow (/root/reference/train.py:29-91; that file does
+not parse, so the body is the build's own): logger -> create_model -> data parallel -> Loss ->
+create_optimizer -> MultiStepLR -> loaders -> epoch loop of train() / validate(), keeping the best
+validation accuracy (the reference leaves "save the model" as a TODO at :91; done here).
+
+Data parallelism: the reference wraps the model in torch.nn.DataParallel over config.GPUS
+(:42-43) with a global batch of BATCH_SIZE * len(gpus) (:65).  Here every GPU is its own process
+(launch with `python -m torch.distributed.run --nproc-per-node G train.py`); each rank loads
+BATCH_SIZE clips per step, gradients are averaged with bucketed RCCL all-reduce overlapped with
+backward (vc3d/ddp.py).  A plain `python train.py` runs one GPU.
+
+Overrides: KEY=VALUE pairs on the command line, e.g. TRAIN.END_EPOCH=1 MODEL.RESNET_TYPE=50.
+"""
+import os
+import sys
+
+import _init_paths  # noqa: F401
+import torch
+import torch.distributed as dist
+import torch.utils.data
+import torch.utils.data.distributed
+
+from core.config import config
+from core.function import train, validate
+from core.loss import Loss
+from dataset.dataset import get_dataset
+from models.model import create_model
+from utils.utils import create_logger, create_optimizer
+from vc3d.ddp import DataParallel3D
+
+
+def apply_overrides(cfg, argv):
+    for item in argv:
+        key, _, val = item.partition("=")
+        node = cfg
+        parts = key.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        old = node[parts[-1]]
+        if isinstance(old, bool):
+            val = val.lower() in ("1", "true", "yes")
+        elif isinstance(old, list):
+            val = [type(old[0])(v) if old else (int(v) if v.lstrip('-').isdigit() else float(v)) for v in val.split(",") if v]
+        elif old is not None:
+            val = type(old)(val)
+        node[parts[-1]] = val
+    return cfg
+
+
+def setup_distributed():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return world, int(os.environ.get("RANK", "0")), torch.device("cuda", local_rank)
+
+
+def make_loader(cfg, if_train, world, rank, length=None):
+    ds = get_dataset(if_train=if_train, config=cfg, length=length)
+    bs = cfg.TRAIN.BATCH_SIZE if if_train else cfg.TEST.BATCH_SIZE
+    sampler = None
+    if world > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank,
+                                                                  shuffle=if_train and cfg.TRAIN.SHUFFLE)
+    return torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=(if_train and cfg.TRAIN.SHUFFLE and sampler is None),
+                                       sampler=sampler, num_workers=cfg.WORKERS, pin_memory=True, drop_last=if_train)
+
+
+def main(argv=None):
+    cfg = apply_overrides(config.clone(), sys.argv[1:] if argv is None else argv)
+    world, rank, dev = setup_distributed()
+    logger = create_logger(cfg, 'train')
+    model = create_model(cfg, is_train=True).to(dev)
+    net = DataParallel3D(model, bucket_mb=cfg.TRAIN.BUCKET_MB) if world > 1 else model
+    criterion = Loss(cfg).to(dev)
+    optimizer = create_optimizer(cfg, model)
+    if optimizer is None:
+        raise SystemExit("unknown TRAIN.OPTIMIZER %r" % cfg.TRAIN.OPTIMIZER)
+    lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, cfg.TRAIN.LR_MILESTONES, cfg.TRAIN.LR_DECAY_RATE)
+    n_train = cfg.get("SYNTH_TRAIN_LEN")
+    n_val = cfg.get("SYNTH_VAL_LEN")
+    train_loader = make_loader(cfg, True, world, rank, n_train)
+    valid_loader = make_loader(cfg, False, world, rank, n_val)
+    best_perf = -1.0
+    for epoch in range(cfg.TRAIN.BEGIN_EPOCH, cfg.TRAIN.END_EPOCH):
+        if world > 1:
+            train_loader.sampler.set_epoch(epoch)
+        train(cfg, train_loader, net, criterion, optimizer, epoch)
+        lr_scheduler.step()  # after the epoch's optimizer steps (the reference steps it first, train.py:81)
+        perf_indicator = validate(cfg, valid_loader, net, criterion, epoch)
+        if perf_indicator > best_perf:
+            best_perf = perf_indicator
+            if rank == 0:
+                path = os.path.join(cfg.OUTPUT_DIR, 'model_best.pth')
+                torch.save({'state_dict': model.state_dict(), 'epoch': epoch, 'perf': best_perf}, path)
+                logger.info('=> saved best model (top-1 %.4f) to %s', best_perf, path)
+    if world > 1:
+        dist.destroy_process_group()
+    return best_perf
+
+
+if __name__ == '__main__':
+    main()
