@@ -70,6 +70,21 @@ int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy,
 int vc_pack_weight(const float* w_master, void* w_fwd, void* w_dgrad /* nullable */, int32_t Co,
                    int32_t taps, int32_t Ci, void* stream);
 
+/* ---- Optimizer step and weight repack over FLAT buffers (all parameters of the model in one fp32
+ * array, gradients in another of the same layout).  Replaces optimizer.step() at reference
+ * lib/core/function.py:82 for the SGD that lib/utils/utils.py:22-29 builds (torch.optim.SGD arithmetic,
+ * dampening 0): one launch for the whole model, which also writes the bf16 shadow of the new
+ * parameters -- a conv weight's slice of the shadow is its forward / wgrad operand.
+ * vc_pack_dgrad_batched then makes every conv's dgrad operand in one launch; the table (the same
+ * int32 [nconv][6] on the host and on the device) holds per conv: element offset in the shadow,
+ * element offset in w_dgrad_flat, Co, taps, Ci, index of its first 64x64 tile. */
+int vc_sgd_step(float* params, const float* grads, float* momentum_buf /* nullable */,
+                void* shadow_bf16 /* nullable */, int64_t n, float lr, float momentum, float weight_decay,
+                int32_t nesterov, void* stream);
+int vc_shadow_bf16(const float* params, void* shadow_bf16, int64_t n, void* stream);
+int vc_pack_dgrad_batched(const void* shadow_bf16, void* w_dgrad_flat, const int32_t* table_dev,
+                          const int32_t* table_host, int32_t nconv, void* stream);
+
 /* ---- Stem: 7x7x7, 3 -> Co (multiple of 64), stride (1,2,2), pad 3.  Replaces
  * reference lib/models/backbone.py:112-113,145.  The clip [N][3][T][H][W] (fp32 or bf16,
  * H and W even) is packed once into a zero-padded space-to-depth bf16 source

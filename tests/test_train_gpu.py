@@ -80,3 +80,48 @@ def test_multi_view_validation_averages_logits():
     assert acc == 1.0
     wrong = (pred + 1) % 6
     assert validate(cfg, [(vids, wrong)], model, Loss(cfg), 0) == 0.0
+
+
+@pytest.mark.parametrize("nesterov", [False, True])
+def test_flat_sgd_matches_torch_sgd(nesterov):
+    """the fused flat optimizer (vc_sgd_step) against torch.optim.SGD on the same gradients, two steps
+    (momentum carries over); afterwards every conv's packed bf16 operands equal a fresh pack of the
+    new master weights (forward layout and the transposed dgrad layout)."""
+    from models.model import create_model
+    from utils.utils import create_optimizer
+    from vc3d.optim import FlatSGD
+    from vc3d import ops
+    torch.manual_seed(0)
+    cfg = make_config(18, 7, OPTIMIZER="sgd", LR=0.1, MOMENTUM=0.9, WD=0.01, NESTEROV=nesterov)
+    model = create_model(cfg, True).cuda().train()
+    opt = create_optimizer(cfg, model)
+    assert isinstance(opt, FlatSGD)
+    x = torch.randn(4, 3, 4, 32, 32).cuda()
+    y = torch.randint(0, 7, (4,)).cuda()
+    _, score, _ = model(x)
+    F.cross_entropy(score, y).backward()
+    names = [n for n, _ in model.named_parameters()]
+    ref = [p.detach().cpu().clone().requires_grad_() for p in model.parameters()]
+    for r, p in zip(ref, model.parameters()):
+        r.grad = p.grad.detach().cpu().clone()
+    topt = torch.optim.SGD(ref, lr=0.1, momentum=0.9, weight_decay=0.01, nesterov=nesterov)
+    for _ in range(2):
+        opt.step()
+        topt.step()
+    torch.cuda.synchronize()
+    for n, r, p in zip(names, ref, model.parameters()):
+        assert torch.allclose(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6), n
+    eng = model.backbone.engine
+    for cb in eng.all_convbn():
+        if cb is eng.stem:
+            continue
+        wf, wd = ops.pack_weight(cb.conv.weight)
+        assert torch.equal(cb.wf, wf) and torch.equal(cb.wd, wd), cb.name
+        assert cb.weights()[0] is cb.wf  # current: no repack on the next forward
+    # training continues through the views: a further forward/backward/step changes the loss
+    opt.zero_grad()
+    _, score, _ = model(x)
+    loss = F.cross_entropy(score, y)
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss)

@@ -306,6 +306,37 @@ int vc_pack_weight(const float* w_master, void* w_fwd, void* w_dgrad, int32_t Co
     return vc_ew_pack_weight(w_master, w_fwd, w_dgrad, Co, taps, Ci, S(stream));
 }
 
+/* ------------------------------------------------------------------ flat-buffer optimizer and weight repack */
+int vc_sgd_step(float* params, const float* grads, float* momentum_buf, void* shadow_bf16, int64_t n, float lr,
+                float momentum, float weight_decay, int32_t nesterov, void* stream) {
+    VC_REQUIRE(params && grads && n > 0, "sgd_step: bad arguments");
+    VC_REQUIRE(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) % 16 == 0 &&
+                   (uintptr_t)shadow_bf16 % 8 == 0,
+               "sgd_step: buffers must be 16-byte aligned");
+    VC_REQUIRE(!nesterov || (momentum_buf && momentum > 0.f), "sgd_step: nesterov needs momentum");
+    return vc_ew_sgd_step(params, grads, momentum_buf, shadow_bf16, (long)n, lr, momentum, weight_decay, nesterov,
+                          S(stream));
+}
+int vc_shadow_bf16(const float* params, void* shadow_bf16, int64_t n, void* stream) {
+    VC_REQUIRE(params && shadow_bf16 && n > 0, "shadow_bf16: bad arguments");
+    return vc_ew_shadow(params, shadow_bf16, (long)n, S(stream));
+}
+int vc_pack_dgrad_batched(const void* shadow_bf16, void* w_dgrad_flat, const int32_t* table_dev, const int32_t* table_host,
+                          int32_t nconv, void* stream) {
+    VC_REQUIRE(shadow_bf16 && w_dgrad_flat && table_dev && table_host && nconv > 0, "pack_dgrad_batched: bad arguments");
+    long tiles = 0;
+    for (int i = 0; i < nconv; ++i) {
+        const int32_t* t = table_host + i * 6;
+        VC_REQUIRE(t[0] >= 0 && t[1] >= 0 && t[2] > 0 && t[3] > 0 && t[4] > 0 && t[2] % 64 == 0 && t[4] % 64 == 0 &&
+                       t[0] % 8 == 0 && t[1] % 8 == 0,
+                   "pack_dgrad_batched: entry %d: channels must be multiples of 64, offsets of 8", i);
+        VC_REQUIRE(t[5] == tiles, "pack_dgrad_batched: entry %d: first tile %d, expected %ld", i, t[5], tiles);
+        tiles += (long)t[3] * (t[2] / 64) * (t[4] / 64);
+    }
+    VC_REQUIRE(tiles < (1l << 31), "pack_dgrad_batched: too many tiles");
+    return vc_ew_pack_dgrad_batched(shadow_bf16, w_dgrad_flat, table_dev, nconv, (int)tiles, S(stream));
+}
+
 /* ------------------------------------------------------------------ stem */
 static int stem_check(int N, int T, int H, int W, int Co) {
     VC_REQUIRE(N > 0 && T > 0 && H > 0 && W > 0, "stem: bad dims");

@@ -39,3 +39,7 @@ int vc_ew_nsc_to_ncs(const void* in, void* out, int out_is_bf16, int N, int C, l
 int vc_ew_pack_weight(const float* w, void* wf, void* wd, int Co, int taps, int Ci, hipStream_t s);
 int vc_ew_stem_pack_weight(const float* w, void* ws, int Co, hipStream_t s);
 int vc_ew_stem_unpack_wgrad(const float* dws, float* dw, int Co, hipStream_t s);
+int vc_ew_sgd_step(float* p, const float* g, float* mom, void* shadow, long n, float lr, float momentum, float wd,
+                   int nesterov, hipStream_t s);
+int vc_ew_shadow(const float* p, void* shadow, long n, hipStream_t s);
+int vc_ew_pack_dgrad_batched(const void* shadow, void* wd, const int* table, int nconv, int tiles, hipStream_t s);

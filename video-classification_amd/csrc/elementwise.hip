@@ -583,6 +583,92 @@ __global__ void stem_unpack_wgrad_kernel(const float* __restrict__ dws, float* _
     if (valid) dw[co * 1029 + src] += dws[i];
 }
 
+
+// ------------------------------------------------------------------ optimizer over the flat buffers
+// torch.optim.SGD arithmetic (dampening 0): g = grad + wd*p; buf = momentum*buf + g;
+// p -= lr * (nesterov ? g + momentum*buf : buf).  Also writes the bf16 shadow of the new parameters:
+// a conv weight's slice of it IS its forward / wgrad operand ([Co][taps][Ci], K contiguous).
+__global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ mom, bf16* __restrict__ shadow, long n,
+                                                       float lr, float momentum, float wd, int nesterov) {
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 pv = ((const f32x4*)p)[i];
+        f32x4 gv = ((const f32x4*)g)[i];
+        gv += wd * pv;
+        if (mom != nullptr) {
+            f32x4 mv = ((const f32x4*)mom)[i];
+            mv = momentum * mv + gv;
+            ((f32x4*)mom)[i] = mv;
+            gv = nesterov ? gv + momentum * mv : mv;
+        }
+        pv -= lr * gv;
+        ((f32x4*)p)[i] = pv;
+        if (shadow != nullptr) ((bf16x4*)shadow)[i] = (bf16x4){f2bf(pv[0]), f2bf(pv[1]), f2bf(pv[2]), f2bf(pv[3])};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
+        const long i = (n4 << 2) + threadIdx.x;
+        float pv = p[i], gv = g[i] + wd * pv;
+        if (mom != nullptr) {
+            const float mv = momentum * mom[i] + gv;
+            mom[i] = mv;
+            gv = nesterov ? gv + momentum * mv : mv;
+        }
+        pv -= lr * gv;
+        p[i] = pv;
+        if (shadow != nullptr) shadow[i] = f2bf(pv);
+    }
+}
+
+// fp32 -> bf16 copy of the flat parameters (after a checkpoint load, or with a non-fused optimizer)
+__global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ p, bf16* __restrict__ shadow, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) shadow[i] = f2bf(p[i]);
+}
+
+// All convs in one launch: bf16 [Co][taps][Ci] (slice of the shadow) -> bf16 [Ci][taps][Co] (the dgrad
+// operand).  One 64(co) x 64(ci) tile of one tap per block, transposed through LDS so that both the
+// reads and the writes are 128-byte rows.  table: int32 [nconv][6] = src_off, dst_off, Co, taps, Ci,
+// first tile.
+__global__ __launch_bounds__(256) void pack_dgrad_batched_kernel(const bf16* __restrict__ shadow, bf16* __restrict__ wd,
+                                                                 const int* __restrict__ table, int nconv) {
+    __shared__ bf16 tile[64][66];
+    int e = 0;
+    for (int i = 1; i < nconv; ++i)
+        if (table[i * 6 + 5] <= (int)blockIdx.x) e = i;
+    const int* tb = table + e * 6;
+    const int Co = tb[2], taps = tb[3], Ci = tb[4];
+    int t = (int)blockIdx.x - tb[5];
+    const int nci = Ci >> 6, nco = Co >> 6;
+    const int cib = t % nci;
+    t /= nci;
+    const int cob = t % nco;
+    const int tap = t / nco;
+    const bf16* src = shadow + tb[0];
+    bf16* dst = wd + tb[1];
+    const int r = threadIdx.x >> 2, sg = threadIdx.x & 3;
+    {
+        const bf16x8* q = (const bf16x8*)(src + ((size_t)(cob * 64 + r) * taps + tap) * Ci + cib * 64 + sg * 16);
+        const bf16x8 a = q[0], b = q[1];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            tile[r][sg * 16 + k] = a[k];
+            tile[r][sg * 16 + 8 + k] = b[k];
+        }
+    }
+    __syncthreads();
+    bf16x8 a, b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = tile[sg * 16 + k][r];
+        b[k] = tile[sg * 16 + 8 + k][r];
+    }
+    bf16x8* o = (bf16x8*)(dst + ((size_t)(cib * 64 + r) * taps + tap) * Co + cob * 64 + sg * 16);
+    o[0] = a;
+    o[1] = b;
+}
+
 inline int grid_for(long n, int block = 256, int cap = 256 * 16) {
     long g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -792,5 +878,20 @@ int vc_ew_stem_pack_weight(const float* w, void* ws, int Co, hipStream_t s) {
 }
 int vc_ew_stem_unpack_wgrad(const float* dws, float* dw, int Co, hipStream_t s) {
     VC_LAUNCH(stem_unpack_wgrad_kernel, dim3((Co * 1344 + 255) / 256), dim3(256), 0, s, dws, dw, Co);
+    return VC_CHECK_LAUNCH();
+}
+
+int vc_ew_sgd_step(float* p, const float* g, float* mom, void* shadow, long n, float lr, float momentum, float wd,
+                   int nesterov, hipStream_t s) {
+    VC_LAUNCH(sgd_step_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, s, p, g, mom, (bf16*)shadow, n, lr,
+              momentum, wd, nesterov);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_shadow(const float* p, void* shadow, long n, hipStream_t s) {
+    VC_LAUNCH(shadow_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, p, (bf16*)shadow, n);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_pack_dgrad_batched(const void* shadow, void* wd, const int* table, int nconv, int tiles, hipStream_t s) {
+    VC_LAUNCH(pack_dgrad_batched_kernel, dim3(tiles), dim3(256), 0, s, (const bf16*)shadow, (bf16*)wd, table, nconv);
     return VC_CHECK_LAUNCH();
 }

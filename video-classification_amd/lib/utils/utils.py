@@ -10,12 +10,22 @@ def create_optimizer(cfg, model):
     """SGD(momentum, wd, nesterov) or Adam(lr); None for any other name (reference utils.py:13-36)."""
     name = cfg.TRAIN.OPTIMIZER
     params = [p for p in model.parameters()]
+    if name == 'sgd' and _fusable(model):
+        from vc3d.optim import FlatSGD  # same arithmetic as torch.optim.SGD, one launch for the whole model
+        return FlatSGD(model, lr=cfg.TRAIN.LR, momentum=cfg.TRAIN.MOMENTUM, weight_decay=cfg.TRAIN.WD,
+                       nesterov=cfg.TRAIN.NESTEROV)
     if name == 'sgd':
         return torch.optim.SGD(params, lr=cfg.TRAIN.LR, momentum=cfg.TRAIN.MOMENTUM,
                                weight_decay=cfg.TRAIN.WD, nesterov=cfg.TRAIN.NESTEROV)
     if name == 'adam':
         return torch.optim.Adam(params, lr=cfg.TRAIN.LR)
     return None
+
+
+def _fusable(model):
+    core = model.module if hasattr(model, "module") else model
+    return (hasattr(core, "backbone") and hasattr(core.backbone, "engine") and hasattr(core, "clf_haed")
+            and all(p.is_cuda for p in core.parameters()))
 
 
 class AverageMeter(object):

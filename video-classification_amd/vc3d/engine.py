@@ -42,6 +42,8 @@ class _ConvBN:
         return ops.conv_desc(N, C, T, H, W, self.Co, self.k, self.s, self.p)
 
     def weights(self):
+        """(forward / wgrad operand, dgrad operand), repacked when the master changed.  A fused
+        optimizer step (vc3d/optim.py) refreshes both itself and records the version it packed."""
         w = self.conv.weight
         if self.wver != w._version or self.wf is None or self.wf.device != w.device:
             self.wf, self.wd = ops.pack_weight(w, want_dgrad=True)
@@ -72,6 +74,10 @@ class R3DEngine:
                     ds = _ConvBN(blk.downsample[0], blk.downsample[1], pre + ".downsample")
                 self.blocks.append((cbs, ds))
         self.flat_grad = None
+        self.flat_param = None   # fp32 master of every parameter, same order / offsets as flat_grad
+        self.flat_shadow = None  # bf16 copy of flat_param (conv slices = forward / wgrad operands)
+        self.flat_wd = None      # bf16 dgrad operands of every conv, packed by one launch
+        self.param_epoch = 0     # bumped by a fused optimizer step (memory changed behind torch's back)
         self.grad_views = None
         self.grad_ready_cb = None  # set by the data-parallel wrapper: cb(param)
         self.backward_done_cb = None
@@ -110,28 +116,67 @@ class R3DEngine:
         gradients come before the backbone's."""
         plist = list(extra_first) + self.params_backward_order()
         dev = plist[0].device
-        total = sum(p.numel() for p in plist)
+        pad = lambda n: (n + 63) // 64 * 64  # every parameter starts on a 256-byte (fp32) / 128-byte (bf16) line
+        total = sum(pad(p.numel()) for p in plist)
         self.flat_grad = torch.zeros(total, dtype=F32, device=dev)
+        self.flat_param = torch.zeros(total, dtype=F32, device=dev)
         self.grad_views = {}
         self.grad_ranges = []
+        self.param_off = {}
         off = 0
         for p in plist:
             n = p.numel()
             seg = self.flat_grad[off:off + n]
+            pseg = self.flat_param[off:off + n]
             if p.dim() == 5:
                 Co, Ci, kt, kh, kw = p.shape
                 v = seg.view(Co, kt, kh, kw, Ci).permute(0, 4, 1, 2, 3)
-                if v.stride() != p.stride() and p.numel() > 1:
-                    # parameter is not channels_last_3d (e.g. freshly loaded): convert it in place
-                    with torch.no_grad():
-                        p.data = p.data.contiguous(memory_format=torch.channels_last_3d)
+                pv = pseg.view(Co, kt, kh, kw, Ci).permute(0, 4, 1, 2, 3)
             else:
                 v = seg.view(p.shape)
+                pv = pseg.view(p.shape)
+            # the parameter becomes a view of the flat master (conv weights: channels_last_3d strides)
+            with torch.no_grad():
+                pv.copy_(p.data)
+                p.data = pv
             self.grad_views[id(p)] = v
             self.grad_ranges.append((p, off, n))
-            off += n
+            self.param_off[id(p)] = off
+            off += pad(n)
         self.plist = plist
+        self.flat_shadow = None
+        self.flat_wd = None
         return self.flat_grad
+
+    def setup_flat_weights(self):
+        """bf16 shadow of the flat master + the dgrad operands of every conv (one buffer, one table)."""
+        dev = self.flat_param.device
+        self.flat_shadow = torch.empty(self.flat_param.numel(), dtype=BF16, device=dev)
+        rows, off_d, tiles = [], 0, 0
+        self.wd_ranges = []
+        for cb in self.all_convbn():
+            if cb is self.stem:
+                continue
+            w = cb.conv.weight
+            taps = cb.k[0] * cb.k[1] * cb.k[2]
+            rows.append([self.param_off[id(w)], off_d, cb.Co, taps, cb.Ci, tiles])
+            self.wd_ranges.append((cb, self.param_off[id(w)], off_d, w.numel()))
+            off_d += w.numel()
+            tiles += taps * (cb.Co // 64) * (cb.Ci // 64)
+        self.flat_wd = torch.empty(off_d, dtype=BF16, device=dev)
+        self.wd_table_host = torch.tensor(rows, dtype=torch.int32).contiguous()
+        self.wd_table_dev = self.wd_table_host.to(dev)
+
+    def refresh_packed_weights(self):
+        """after a fused optimizer step wrote flat_param AND flat_shadow: one launch makes every dgrad
+        operand, and every conv's cached operands become views of the flat buffers."""
+        ops.pack_dgrad_batched(self.flat_shadow, self.flat_wd, self.wd_table_dev, self.wd_table_host)
+        for cb, off_s, off_d, n in self.wd_ranges:
+            taps = cb.k[0] * cb.k[1] * cb.k[2]
+            cb.wf = self.flat_shadow[off_s:off_s + n].view(cb.Co, taps * cb.Ci)
+            cb.wd = self.flat_wd[off_d:off_d + n].view(cb.Ci, taps * cb.Co)
+            cb.wver = cb.conv.weight._version
+        self.param_epoch += 1
 
     def _bind_grads(self):
         """point every param.grad at its flat view (keeping accumulated values)."""
@@ -178,7 +223,7 @@ class R3DEngine:
                                 bn.running_mean if bn.track_running_stats else None,
                                 bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps)
             if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+                self._nbt.append(bn.num_batches_tracked)
             return p
         ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version)
         if cb.eval_params is None or cb.eval_ver != ver or cb.eval_params.device != bn.weight.device:
@@ -207,13 +252,13 @@ class R3DEngine:
         x = x.contiguous()
         N, _, T, H, W = x.shape
         dev = x.device
-        nbn = sum(1 for _ in self.all_convbn())
+        self._nbt = []
         stats_pool = _StatsPool(sum(cb.Co for cb in self.all_convbn()), dev) if training else None
         st = self.stem
         w = st.conv.weight
-        if self.stem_wver != w._version or self.stem_ws is None or self.stem_ws.device != dev:
+        if self.stem_wver != (w._version, self.param_epoch) or self.stem_ws is None or self.stem_ws.device != dev:
             self.stem_ws = ops.stem_pack_weight(w)
-            self.stem_wver = w._version
+            self.stem_wver = (w._version, self.param_epoch)
         xs = ops.stem_pack_input(x)
         stats0 = stats_pool.take(st.Co) if training else None
         y0 = ops.stem_fwd(xs, self.stem_ws, N, T, H, W, st.Co, stats=stats0)
@@ -253,6 +298,8 @@ class R3DEngine:
             if save:
                 saved["blocks"].append((xin, recs, dsrec))
             cur = out
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)  # one launch for all BatchNorm step counters
         Nn, To, Ho, Wo, Cf = cur.shape
         feat = ops.gavgpool_fwd(cur, Nn, To * Ho * Wo, Cf)
         self._t("final", x=cur, feat=feat)

@@ -158,6 +158,37 @@ def conv3d_wgrad(d, x, dy, dw):
     return dw
 
 
+def sgd_step(params, grads, mom, shadow, lr, momentum, wd, nesterov):
+    """fused torch.optim.SGD step over flat fp32 buffers; also writes the bf16 shadow."""
+    n = params.numel()
+    _chk(params, F32, n, "flat params")
+    _chk(grads, F32, n, "flat grads")
+    _chk(mom, F32, n, "momentum buffer")
+    _chk(shadow, BF16, n, "bf16 shadow")
+    check(lib.vc_sgd_step(ptr(params), ptr(grads), ptr(mom), ptr(shadow), n, float(lr), float(momentum), float(wd),
+                          1 if nesterov else 0, cur_stream()), "vc_sgd_step")
+
+
+def shadow_bf16(params, shadow):
+    _chk(params, F32, name="flat params")
+    _chk(shadow, BF16, params.numel(), "bf16 shadow")
+    check(lib.vc_shadow_bf16(ptr(params), ptr(shadow), params.numel(), cur_stream()), "vc_shadow_bf16")
+
+
+def pack_dgrad_batched(shadow, wd_flat, table_dev, table_host):
+    _chk(shadow, BF16, name="bf16 shadow")
+    _chk(wd_flat, BF16, name="dgrad weights")
+    _chk(table_dev, torch.int32, table_host.numel(), "table")
+    if table_host.is_cuda or table_host.dtype != torch.int32 or not table_host.is_contiguous():
+        raise capi.Vc3dError("pack_dgrad_batched: host table must be a contiguous CPU int32 tensor")
+    th = table_host.view(-1, 6)
+    for src, dst, Co, taps, Ci, _ in th.tolist():  # the kernel trusts these offsets
+        if src + Co * taps * Ci > shadow.numel() or dst + Co * taps * Ci > wd_flat.numel():
+            raise capi.Vc3dError("pack_dgrad_batched: table entry exceeds its buffer")
+    check(lib.vc_pack_dgrad_batched(ptr(shadow), ptr(wd_flat), ptr(table_dev), table_host.data_ptr(), th.shape[0],
+                                    cur_stream()), "vc_pack_dgrad_batched")
+
+
 # ------------------------------------------------------------------ stem
 def stem_pack_input(x):
     """x: [N][3][T][H][W] fp32 or bf16 (contiguous) -> padded space-to-depth bf16 source."""
