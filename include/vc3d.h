@@ -130,6 +130,14 @@ int vc_maxpool3d_fwd(const vc_pool3d_desc* d, const void* y,
                      uint8_t* argmax, void* stream);
 int vc_maxpool3d_bwd(const vc_pool3d_desc* d, const void* dout, const uint8_t* argmax, void* din,
                      void* stream);
+/* BatchNorm+ReLU backward THROUGH the max pool (the stem, reference backbone.py:146-148 in reverse): the
+ * gradient entering BN+ReLU is gathered from the pooled gradient and the arg-max map on the fly instead of
+ * being materialised by vc_maxpool3d_bwd.  `d` describes the pool (its input = y's geometry); ReLU mask
+ * recomputed from y (mask mode 2).  Use with vc_bn_bwd_finalize in between. */
+int vc_bn_bwd_reduce_pooled(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
+                            const float* params, float* sums, void* stream);
+int vc_bn_bwd_apply_pooled(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
+                           const float* params, const float* coef, void* dy, void* stream);
 int vc_gavgpool_fwd(const void* in, float* out, int32_t N, int32_t S, int32_t C, void* stream);
 int vc_gavgpool_bwd(const float* dfeat, void* din, int32_t N, int32_t S, int32_t C, void* stream);
 

@@ -313,3 +313,42 @@ def test_shape_errors_are_loud():
         ops.stem_pack_input(torch.zeros(1, 3, 2, 5, 4, device="cuda"))  # odd H
     with pytest.raises(capi.Vc3dError):
         ops.bn_apply(torch.zeros(8, 64), torch.zeros(4, 64), 64)  # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 4, 8, 8), (1, 64, 5, 7, 9), (2, 128, 1, 6, 6)])
+def test_bn_bwd_through_pool_matches_unfused(shape):
+    """stem backward: BN+ReLU backward fed by a gather from the pooled gradient == max-pool backward
+    followed by BN+ReLU backward (mask recomputed), and == torch autograd through relu(bn(y)) -> max_pool3d."""
+    _need_gpu()
+    from vc3d import ops
+    N, C, T, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    y = bf16_round(torch.randn(N, C, T, H, W, generator=g) * 1.3 + 0.2)
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    yd = to_nthwc_dev(y)
+    stats = ops.bn_stats(yd, C)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    prm = ops.bn_finalize(stats, yd.numel() // C, gamma.cuda(), beta.cuda(), rm, rv, 0.1, 1e-5)
+    pd = ops.pool_desc(N, C, T, H, W)
+    pooled, idx = ops.maxpool3d_fwd(pd, yd, prm)
+    dp = bf16_round(torch.randn(N, C, *pd.out_dims(), generator=g))
+    dpd = to_nthwc_dev(dp)
+    # unfused
+    din = ops.maxpool3d_bwd(pd, dpd, idx)
+    dg0, db0 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dy0, _ = ops.bn_bwd(yd, din, prm, C, dg0, db0, mask=2)
+    # fused
+    dg1, db1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dy1 = ops.bn_bwd_pooled(pd, yd, dpd, idx, prm, C, dg1, db1)
+    # the unfused path rounds the pool-input gradient (a sum over up to 8 windows) to bf16, the fused one keeps it in fp32
+    assert rel_l2(dy1.float().cpu(), dy0.float().cpu()) <= TOL_BF16
+    assert rel_l2(dg1.cpu(), dg0.cpu()) <= 2e-3 and rel_l2(db1.cpu(), db0.cpu()) <= 2e-3
+    # torch reference of the whole chain
+    yr = y.clone().requires_grad_()
+    bn = torch.nn.BatchNorm3d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    F.max_pool3d(bf16_round(torch.relu(bn(yr)).detach()) + (torch.relu(bn(yr)) - torch.relu(bn(yr)).detach()), 3, 2, 1).backward(dp)
+    assert rel_l2(from_nthwc(dy1), yr.grad) <= 2e-2

@@ -511,6 +511,24 @@ int vc_maxpool3d_bwd(const vc_pool3d_desc* d, const void* dout, const uint8_t* a
     VC_REQUIRE(dout && argmax && din, "maxpool3d_bwd: null pointer");
     return vc_ew_maxpool_bwd(dout, argmax, din, g, S(stream));
 }
+int vc_bn_bwd_reduce_pooled(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
+                            const float* params, float* sums, void* stream) {
+    VcPoolGeom g;
+    int rc = pool_geom(d, g);
+    if (rc) return rc;
+    VC_REQUIRE(y && dpooled && argmax && params && sums, "bn_bwd_reduce_pooled: null pointer");
+    VC_REQUIRE(pow2_channels(g.C), "bn: C=%d must be a power of two in [64, 2048]", g.C);
+    return vc_ew_bn_bwd_reduce_pooled(y, dpooled, argmax, params, sums, g, S(stream));
+}
+int vc_bn_bwd_apply_pooled(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
+                           const float* params, const float* coef, void* dy, void* stream) {
+    VcPoolGeom g;
+    int rc = pool_geom(d, g);
+    if (rc) return rc;
+    VC_REQUIRE(y && dpooled && argmax && params && coef && dy, "bn_bwd_apply_pooled: null pointer");
+    VC_REQUIRE(g.C % 8 == 0, "bn_bwd_apply_pooled: C=%d must be a multiple of 8", g.C);
+    return vc_ew_bn_bwd_apply_pooled(y, dpooled, argmax, params, coef, dy, g, S(stream));
+}
 int vc_gavgpool_fwd(const void* in, float* out, int32_t N, int32_t Sp, int32_t C, void* stream) {
     VC_REQUIRE(in && out && N > 0 && Sp > 0 && C > 0, "gavgpool_fwd: bad arguments");
     return vc_ew_avgpool_fwd(in, out, N, Sp, C, S(stream));

@@ -68,13 +68,22 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16x8* __restrict_
     const float* scale = params + 2 * C;
     const float* shift = params + 3 * C;
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
-        const int c = (int)((i * 8) % C);
+    // the stride is a multiple of the channel groups per row whenever C/8 divides 256 (every ResNet
+    // width): then a thread keeps its 8 channels for the whole loop and loads their parameters once
+    const bool fixed = ((stride * 8) % C) == 0;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = (int)((i * 8) % C);
+    f32x4 s0 = *(const f32x4*)(scale + c), s1 = *(const f32x4*)(scale + c + 4);
+    f32x4 b0 = *(const f32x4*)(shift + c), b1 = *(const f32x4*)(shift + c + 4);
+    for (; i < n8; i += stride) {
+        if (!fixed) {
+            c = (int)((i * 8) % C);
+            s0 = *(const f32x4*)(scale + c), s1 = *(const f32x4*)(scale + c + 4);
+            b0 = *(const f32x4*)(shift + c), b1 = *(const f32x4*)(shift + c + 4);
+        }
         float f[8], r[8];
         unpack8(y[i], f);
         if (RES) unpack8(res[i], r);
-        const f32x4 s0 = *(const f32x4*)(scale + c), s1 = *(const f32x4*)(scale + c + 4);
-        const f32x4 b0 = *(const f32x4*)(shift + c), b1 = *(const f32x4*)(shift + c + 4);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float v = f[k] * (k < 4 ? s0[k] : s1[k - 4]) + (k < 4 ? b0[k] : b1[k - 4]);
@@ -260,6 +269,23 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, fl
 
 // BN backward apply: dy = scale * (g - c1 - xhat*c2); optionally writes g (the masked
 // incoming gradient, which is also the gradient of the residual branch).
+struct BnBwdCoef {  // per-lane constants of 8 consecutive channels
+    float mean[8], invstd[8], scale[8], shift[8], c1[8], c2[8];
+};
+__device__ __forceinline__ void load_bwd_coef(BnBwdCoef& k, const float* params, const float* coef, int C, int c) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x4 m = *(const f32x4*)(params + c + 4 * h), iv = *(const f32x4*)(params + C + c + 4 * h),
+                    sc = *(const f32x4*)(params + 2 * C + c + 4 * h), sh = *(const f32x4*)(params + 3 * C + c + 4 * h),
+                    a = *(const f32x4*)(coef + c + 4 * h), b = *(const f32x4*)(coef + C + c + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            k.mean[4 * h + j] = m[j], k.invstd[4 * h + j] = iv[j], k.scale[4 * h + j] = sc[j];
+            k.shift[4 * h + j] = sh[j], k.c1[4 * h + j] = a[j], k.c2[4 * h + j] = b[j];
+        }
+    }
+}
+
 template <int MASK, bool WRITE_G>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16x8* __restrict__ y, const bf16x8* __restrict__ dz,
                                                            const bf16x8* __restrict__ aux,
@@ -267,21 +293,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16x8* __restr
                                                            const float* __restrict__ coef, bf16x8* __restrict__ dy,
                                                            bf16x8* __restrict__ gout, long n8, int C) {
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
-        const int c = (int)((i * 8) % C);
+    const bool fixed = ((stride * 8) % C) == 0;  // see bn_apply_kernel
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    BnBwdCoef kc;
+    load_bwd_coef(kc, params, coef, C, (int)((i * 8) % C));
+    for (; i < n8; i += stride) {
+        if (!fixed) load_bwd_coef(kc, params, coef, C, (int)((i * 8) % C));
         float f[8], d[8], m[8], o[8];
         unpack8(y[i], f);
         unpack8(dz[i], d);
         if (MASK == 1) unpack8(aux[i], m);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float mean = params[c + k], invstd = params[C + c + k], scale = params[2 * C + c + k],
-                        shift = params[3 * C + c + k];
             float gk = d[k];
             if (MASK == 1) gk = m[k] > 0.f ? gk : 0.f;
-            if (MASK == 2) gk = (f[k] * scale + shift) > 0.f ? gk : 0.f;
-            const float xhat = (f[k] - mean) * invstd;
-            o[k] = scale * (gk - coef[c + k] - xhat * coef[C + c + k]);
+            if (MASK == 2) gk = (f[k] * kc.scale[k] + kc.shift[k]) > 0.f ? gk : 0.f;
+            const float xhat = (f[k] - kc.mean[k]) * kc.invstd[k];
+            o[k] = kc.scale[k] * (gk - kc.c1[k] - xhat * kc.c2[k]);
             d[k] = gk;
         }
         dy[i] = pack8(o);
@@ -410,6 +438,125 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16x8* __restri
                         if ((int)((packed >> (8 * k)) & 0xff) == tap) acc[k] += d[k];
                 }
         din[i] = pack8(acc);
+    }
+}
+
+
+// ------------------------------------------------------------------ BN backward through a max pool (the stem)
+// The gradient entering BN+ReLU is the max-pool input gradient.  Materialising it costs a full-size
+// write and two full-size reads; instead both BN-backward passes gather it from the pooled gradient
+// (1/8 of the size, cache resident): position (t,h,w) takes dout[o] from every window o that contains
+// it and whose stored arg-max tap is this position.  MASK-2 semantics (ReLU mask recomputed from y).
+__device__ __forceinline__ void pool_gather8(float (&acc)[8], const bf16x8* __restrict__ dout,
+                                             const uint8_t* __restrict__ idx, const VcPoolGeom& g, int n, int t, int h,
+                                             int w, int cg, int groups) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    const int to_lo = max(0, (t + g.pt - g.kt + g.st) / g.st), to_hi = min(g.To - 1, (t + g.pt) / g.st);
+    const int ho_lo = max(0, (h + g.ph - g.kh + g.sh) / g.sh), ho_hi = min(g.Ho - 1, (h + g.ph) / g.sh);
+    const int wo_lo = max(0, (w + g.pw - g.kw + g.sw) / g.sw), wo_hi = min(g.Wo - 1, (w + g.pw) / g.sw);
+    for (int to = to_lo; to <= to_hi; ++to)
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                const int tap = ((t + g.pt - to * g.st) * g.kh + (h + g.ph - ho * g.sh)) * g.kw + (w + g.pw - wo * g.sw);
+                const long o = ((((long)n * g.To + to) * g.Ho + ho) * g.Wo + wo) * groups + cg;
+                const uint64_t packed = *(const uint64_t*)(idx + o * 8);
+                float d[8];
+                unpack8(dout[o], d);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((int)((packed >> (8 * k)) & 0xff) == tap) acc[k] += d[k];
+            }
+}
+
+// sums of g and g*xhat over rows, g = pooled-gradient gather * relu mask.  One block = rows_per_block rows.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16x8* __restrict__ y,
+                                                                   const bf16x8* __restrict__ dout,
+                                                                   const uint8_t* __restrict__ idx,
+                                                                   const float* __restrict__ params, float* sums,
+                                                                   VcPoolGeom g, int rows_per_block) {
+    __shared__ float sm[256 * 17];
+    const int C = g.C, groups = C >> 3, rl = 256 / groups;
+    const int cg = threadIdx.x % groups, r = threadIdx.x / groups;
+    const long rows = (long)g.N * g.T * g.H * g.W;
+    float a0[8], a1[8], mean[8], invstd[8], scale[8], shift[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a0[k] = a1[k] = 0.f;
+        mean[k] = params[cg * 8 + k], invstd[k] = params[C + cg * 8 + k];
+        scale[k] = params[2 * C + cg * 8 + k], shift[k] = params[3 * C + cg * 8 + k];
+    }
+    const long row0 = (long)blockIdx.x * rows_per_block;
+    const long row1 = min(rows, row0 + rows_per_block);
+    if (r < rl) {
+        for (long row = row0 + r; row < row1; row += rl) {
+            long pos = row;
+            const int w = (int)(pos % g.W);
+            pos /= g.W;
+            const int h = (int)(pos % g.H);
+            pos /= g.H;
+            const int t = (int)(pos % g.T);
+            const int n = (int)(pos / g.T);
+            float f[8], d[8];
+            unpack8(y[row * groups + cg], f);
+            pool_gather8(d, dout, idx, g, n, t, h, w, cg, groups);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gk = (f[k] * scale[k] + shift[k]) > 0.f ? d[k] : 0.f;
+                a0[k] += gk;
+                a1[k] += gk * (f[k] - mean[k]) * invstd[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sm[threadIdx.x * 17 + k] = a0[k];
+        sm[threadIdx.x * 17 + 8 + k] = a1[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        float* dst = sums + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * C;
+        for (int k = 0; k < 16; ++k) {
+            float s = 0.f;
+            for (int rr = 0; rr < rl; ++rr) s += sm[(rr * groups + threadIdx.x) * 17 + k];
+            atomicAdd(dst + (k < 8 ? 0 : C) + threadIdx.x * 8 + (k & 7), s);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_pooled_kernel(const bf16x8* __restrict__ y,
+                                                                  const bf16x8* __restrict__ dout,
+                                                                  const uint8_t* __restrict__ idx,
+                                                                  const float* __restrict__ params,
+                                                                  const float* __restrict__ coef,
+                                                                  bf16x8* __restrict__ dy, VcPoolGeom g) {
+    const int C = g.C, groups = C >> 3;
+    const long n8 = (long)g.N * g.T * g.H * g.W * groups;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const bool fixed = ((stride * 8) % C) == 0;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    BnBwdCoef kc;
+    load_bwd_coef(kc, params, coef, C, (int)((i * 8) % C));
+    for (; i < n8; i += stride) {
+        if (!fixed) load_bwd_coef(kc, params, coef, C, (int)((i * 8) % C));
+        const int cg = (int)(i % groups);
+        long pos = i / groups;
+        const int w = (int)(pos % g.W);
+        pos /= g.W;
+        const int h = (int)(pos % g.H);
+        pos /= g.H;
+        const int t = (int)(pos % g.T);
+        const int n = (int)(pos / g.T);
+        float f[8], d[8], o[8];
+        unpack8(y[i], f);
+        pool_gather8(d, dout, idx, g, n, t, h, w, cg, groups);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gk = (f[k] * kc.scale[k] + kc.shift[k]) > 0.f ? d[k] : 0.f;
+            const float xhat = (f[k] - kc.mean[k]) * kc.invstd[k];
+            o[k] = kc.scale[k] * (gk - kc.c1[k] - xhat * kc.c2[k]);
+        }
+        dy[i] = pack8(o);
     }
 }
 
@@ -724,7 +871,7 @@ int vc_ew_bn_apply(const void* y, const float* params, const void* res, void* ou
 
 static void reduce_geometry(long rows, int C, int& grid, int& rpb) {
     const int rl = 256 / (C / 8);
-    long want = (rows + (long)rl * 8 - 1) / ((long)rl * 8);  // >= 8 rows per thread
+    long want = (rows + (long)rl * 2 - 1) / ((long)rl * 2);  // >= 2 rows per thread, at most 2048 blocks
     if (want > 2048) want = 2048;
     if (want < 1) want = 1;
     rpb = (int)((rows + want - 1) / want);
@@ -893,5 +1040,21 @@ int vc_ew_shadow(const float* p, void* shadow, long n, hipStream_t s) {
 }
 int vc_ew_pack_dgrad_batched(const void* shadow, void* wd, const int* table, int nconv, int tiles, hipStream_t s) {
     VC_LAUNCH(pack_dgrad_batched_kernel, dim3(tiles), dim3(256), 0, s, (const bf16*)shadow, (bf16*)wd, table, nconv);
+    return VC_CHECK_LAUNCH();
+}
+
+int vc_ew_bn_bwd_reduce_pooled(const void* y, const void* dout, const uint8_t* idx, const float* params, float* sums,
+                               const VcPoolGeom& g, hipStream_t s) {
+    int grid, rpb;
+    reduce_geometry((long)g.N * g.T * g.H * g.W, g.C, grid, rpb);
+    VC_LAUNCH(bn_bwd_reduce_pooled_kernel, dim3(grid), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)dout, idx, params,
+              sums, g, rpb);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_bn_bwd_apply_pooled(const void* y, const void* dout, const uint8_t* idx, const float* params, const float* coef,
+                              void* dy, const VcPoolGeom& g, hipStream_t s) {
+    const long n8 = (long)g.N * g.T * g.H * g.W * (g.C / 8);
+    VC_LAUNCH(bn_bwd_apply_pooled_kernel, dim3(grid_for(n8)), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)dout, idx,
+              params, coef, (bf16x8*)dy, g);
     return VC_CHECK_LAUNCH();
 }

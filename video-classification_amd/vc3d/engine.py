@@ -366,10 +366,11 @@ class R3DEngine:
         # stem: max pool -> BN+ReLU (mask recomputed) -> conv wgrad
         xs, y0, p0, pd, idx, (N, T, H, W) = saved["stem"]
         st = self.stem
-        din = ops.maxpool3d_bwd(pd, g, idx)
-        self._t("conv1", dpooled=g, dz=din)
-        dy0, _ = ops.bn_bwd(y0, din, p0, st.Co, self.gview(st.bn.weight), self.gview(st.bn.bias), mask=2,
-                            sums=sums_pool.take(st.Co))
+        if self.trace is not None:  # tests look at the materialised pool-input gradient as well
+            din = ops.maxpool3d_bwd(pd, g, idx)
+            self._t("conv1", dpooled=g, dz=din)
+        dy0 = ops.bn_bwd_pooled(pd, y0, g, idx, p0, st.Co, self.gview(st.bn.weight), self.gview(st.bn.bias),
+                                sums=sums_pool.take(st.Co))
         self._ready(st.bn.weight, st.bn.bias)
         if self._stem_scratch is None or self._stem_scratch.device != dev or self._stem_scratch.shape[0] != st.Co:
             self._stem_scratch = torch.zeros(st.Co, ops.STEM_K, dtype=F32, device=dev)
