@@ -517,6 +517,7 @@ int vc_bn_bwd_reduce_pooled(const vc_pool3d_desc* d, const void* y, const void* 
     int rc = pool_geom(d, g);
     if (rc) return rc;
     VC_REQUIRE(y && dpooled && argmax && params && sums, "bn_bwd_reduce_pooled: null pointer");
+    VC_REQUIRE((long long)g.N * g.T * g.H < (1ll << 31), "bn_bwd_reduce_pooled: too many rows");
     VC_REQUIRE(pow2_channels(g.C), "bn: C=%d must be a power of two in [64, 2048]", g.C);
     return vc_ew_bn_bwd_reduce_pooled(y, dpooled, argmax, params, sums, g, S(stream));
 }
@@ -526,7 +527,9 @@ int vc_bn_bwd_apply_pooled(const vc_pool3d_desc* d, const void* y, const void* d
     int rc = pool_geom(d, g);
     if (rc) return rc;
     VC_REQUIRE(y && dpooled && argmax && params && coef && dy, "bn_bwd_apply_pooled: null pointer");
-    VC_REQUIRE(g.C % 8 == 0, "bn_bwd_apply_pooled: C=%d must be a multiple of 8", g.C);
+    VC_REQUIRE(g.kt <= 2 * g.st && g.kh <= 2 * g.sh && g.kw <= 2 * g.sw,
+               "bn_bwd_apply_pooled: kernel must be <= 2*stride (at most 2 windows per axis)");
+    VC_REQUIRE(pow2_channels(g.C), "bn: C=%d must be a power of two in [64, 2048]", g.C);
     return vc_ew_bn_bwd_apply_pooled(y, dpooled, argmax, params, coef, dy, g, S(stream));
 }
 int vc_gavgpool_fwd(const void* in, float* out, int32_t N, int32_t Sp, int32_t C, void* stream) {

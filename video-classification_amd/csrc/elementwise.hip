@@ -447,38 +447,71 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16x8* __restri
 // write and two full-size reads; instead both BN-backward passes gather it from the pooled gradient
 // (1/8 of the size, cache resident): position (t,h,w) takes dout[o] from every window o that contains
 // it and whose stored arg-max tap is this position.  MASK-2 semantics (ReLU mask recomputed from y).
-__device__ __forceinline__ void pool_gather8(float (&acc)[8], const bf16x8* __restrict__ dout,
-                                             const uint8_t* __restrict__ idx, const VcPoolGeom& g, int n, int t, int h,
-                                             int w, int cg, int groups) {
+// Both kernels walk (n,t,h) rows: the row's coordinates and its window ranges along t and h are
+// wave-uniform (scalar arithmetic); only w and the channel group vary per lane.
+struct PoolRow {
+    int n, t, h, to_lo, to_hi, ho_lo, ho_hi;
+};
+__device__ __forceinline__ PoolRow pool_row(const VcPoolGeom& g, int row) {
+    PoolRow r;
+    r.h = row % g.H;
+    const int q = row / g.H;
+    r.t = q % g.T;
+    r.n = q / g.T;
+    r.to_lo = max(0, (r.t + g.pt - g.kt + g.st) / g.st), r.to_hi = min(g.To - 1, (r.t + g.pt) / g.st);
+    r.ho_lo = max(0, (r.h + g.ph - g.kh + g.sh) / g.sh), r.ho_hi = min(g.Ho - 1, (r.h + g.ph) / g.sh);
+    return r;
+}
+// Gradient of the pool input at (row r, w), 8 channels: at most 2 windows per axis contain a position
+// (the host checks kernel <= 2*stride), so the 8 candidates are laid out straight-line: all their loads
+// are issued before the first compare instead of one dependent load pair per loop trip.
+__device__ __forceinline__ void pool_gather_row8(float (&acc)[8], const bf16x8* __restrict__ dout,
+                                                 const uint8_t* __restrict__ idx, const VcPoolGeom& g,
+                                                 const PoolRow& r, int w, int cg, int groups) {
+    const int wo_lo = max(0, (w + g.pw - g.kw + g.sw) / g.sw), wo_hi = min(g.Wo - 1, (w + g.pw) / g.sw);
+    uint64_t pk[8];
+    bf16x8 dv[8];
+    int tp[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int to = r.to_lo + (j >> 2), ho = r.ho_lo + ((j >> 1) & 1), wo = wo_lo + (j & 1);
+        const bool ok = to <= r.to_hi && ho <= r.ho_hi && wo <= wo_hi;
+        tp[j] = ok ? ((r.t + g.pt - to * g.st) * g.kh + (r.h + g.ph - ho * g.sh)) * g.kw + (w + g.pw - wo * g.sw) : 256;
+        pk[j] = 0;
+        dv[j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) {
+            const long o = ((((long)r.n * g.To + to) * g.Ho + ho) * g.Wo + wo) * groups + cg;
+            pk[j] = *(const uint64_t*)(idx + o * 8);
+            dv[j] = dout[o];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    const int to_lo = max(0, (t + g.pt - g.kt + g.st) / g.st), to_hi = min(g.To - 1, (t + g.pt) / g.st);
-    const int ho_lo = max(0, (h + g.ph - g.kh + g.sh) / g.sh), ho_hi = min(g.Ho - 1, (h + g.ph) / g.sh);
-    const int wo_lo = max(0, (w + g.pw - g.kw + g.sw) / g.sw), wo_hi = min(g.Wo - 1, (w + g.pw) / g.sw);
-    for (int to = to_lo; to <= to_hi; ++to)
-        for (int ho = ho_lo; ho <= ho_hi; ++ho)
-            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-                const int tap = ((t + g.pt - to * g.st) * g.kh + (h + g.ph - ho * g.sh)) * g.kw + (w + g.pw - wo * g.sw);
-                const long o = ((((long)n * g.To + to) * g.Ho + ho) * g.Wo + wo) * groups + cg;
-                const uint64_t packed = *(const uint64_t*)(idx + o * 8);
-                float d[8];
-                unpack8(dout[o], d);
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if ((int)((packed >> (8 * k)) & 0xff) == tap) acc[k] += d[k];
-            }
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if ((int)((pk[j] >> (8 * k)) & 0xff) == tp[j]) acc[k] += bf2f(dv[j][k]);
+    }
 }
 
-// sums of g and g*xhat over rows, g = pooled-gradient gather * relu mask.  One block = rows_per_block rows.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16x8* __restrict__ y,
+// sums of g and g*xhat.  The pool-input gradient is non-zero only at arg-max positions, so the sums are
+// taken from the POOLED side (1/8 of the elements): every pooled element adds its gradient at its own
+// arg-max input position (found from the stored tap), masked by the recomputed ReLU.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16* __restrict__ y,
                                                                    const bf16x8* __restrict__ dout,
                                                                    const uint8_t* __restrict__ idx,
                                                                    const float* __restrict__ params, float* sums,
-                                                                   VcPoolGeom g, int rows_per_block) {
+                                                                   VcPoolGeom g) {
     __shared__ float sm[256 * 17];
-    const int C = g.C, groups = C >> 3, rl = 256 / groups;
-    const int cg = threadIdx.x % groups, r = threadIdx.x / groups;
-    const long rows = (long)g.N * g.T * g.H * g.W;
+    __shared__ int lut[256];  // tap -> input row offset from the window origin
+    const int C = g.C, groups = C >> 3;
+    const int cg = threadIdx.x % groups;  // fixed per lane: the grid stride is a multiple of `groups`
+    {
+        const int tap = threadIdx.x;
+        const int c = tap % g.kw, b = (tap / g.kw) % g.kh, a = tap / (g.kw * g.kh);
+        lut[tap] = (a * g.H + b) * g.W + c;
+    }
     float a0[8], a1[8], mean[8], invstd[8], scale[8], shift[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -486,26 +519,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16x8*
         mean[k] = params[cg * 8 + k], invstd[k] = params[C + cg * 8 + k];
         scale[k] = params[2 * C + cg * 8 + k], shift[k] = params[3 * C + cg * 8 + k];
     }
-    const long row0 = (long)blockIdx.x * rows_per_block;
-    const long row1 = min(rows, row0 + rows_per_block);
-    if (r < rl) {
-        for (long row = row0 + r; row < row1; row += rl) {
-            long pos = row;
-            const int w = (int)(pos % g.W);
-            pos /= g.W;
-            const int h = (int)(pos % g.H);
-            pos /= g.H;
-            const int t = (int)(pos % g.T);
-            const int n = (int)(pos / g.T);
-            float f[8], d[8];
-            unpack8(y[row * groups + cg], f);
-            pool_gather8(d, dout, idx, g, n, t, h, w, cg, groups);
+    __syncthreads();
+    const long total = (long)g.N * g.To * g.Ho * g.Wo * groups;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        long pos = i / groups;
+        const int wo = (int)(pos % g.Wo);
+        pos /= g.Wo;
+        const int ho = (int)(pos % g.Ho);
+        pos /= g.Ho;
+        const int to = (int)(pos % g.To);
+        const int n = (int)(pos / g.To);
+        const long origin = (((long)n * g.T + (to * g.st - g.pt)) * g.H + (ho * g.sh - g.ph)) * g.W + (wo * g.sw - g.pw);
+        const uint64_t packed = *(const uint64_t*)(idx + i * 8);
+        float d[8];
+        unpack8(dout[i], d);
+        float yv[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float gk = (f[k] * scale[k] + shift[k]) > 0.f ? d[k] : 0.f;
-                a0[k] += gk;
-                a1[k] += gk * (f[k] - mean[k]) * invstd[k];
-            }
+        for (int k = 0; k < 8; ++k) {
+            const int tap = (int)((packed >> (8 * k)) & 0xff);
+            yv[k] = bf2f(y[(origin + lut[tap]) * C + cg * 8 + k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float gk = (yv[k] * scale[k] + shift[k]) > 0.f ? d[k] : 0.f;
+            a0[k] += gk;
+            a1[k] += gk * (yv[k] - mean[k]) * invstd[k];
         }
     }
 #pragma unroll
@@ -515,6 +554,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16x8*
     }
     __syncthreads();
     if (threadIdx.x < groups) {
+        const int rl = 256 / groups;
         float* dst = sums + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * C;
         for (int k = 0; k < 16; ++k) {
             float s = 0.f;
@@ -531,32 +571,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pooled_kernel(const bf16x8* 
                                                                   const float* __restrict__ coef,
                                                                   bf16x8* __restrict__ dy, VcPoolGeom g) {
     const int C = g.C, groups = C >> 3;
-    const long n8 = (long)g.N * g.T * g.H * g.W * groups;
-    const long stride = (long)gridDim.x * blockDim.x;
-    const bool fixed = ((stride * 8) % C) == 0;
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cg = threadIdx.x % groups;
+    const int per_row = g.W * groups;
+    const int nrows = g.N * g.T * g.H;
     BnBwdCoef kc;
-    load_bwd_coef(kc, params, coef, C, (int)((i * 8) % C));
-    for (; i < n8; i += stride) {
-        if (!fixed) load_bwd_coef(kc, params, coef, C, (int)((i * 8) % C));
-        const int cg = (int)(i % groups);
-        long pos = i / groups;
-        const int w = (int)(pos % g.W);
-        pos /= g.W;
-        const int h = (int)(pos % g.H);
-        pos /= g.H;
-        const int t = (int)(pos % g.T);
-        const int n = (int)(pos / g.T);
-        float f[8], d[8], o[8];
-        unpack8(y[i], f);
-        pool_gather8(d, dout, idx, g, n, t, h, w, cg, groups);
+    load_bwd_coef(kc, params, coef, C, cg * 8);
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const PoolRow r = pool_row(g, row);
+        const bf16x8* yrow = y + (long)row * per_row;
+        bf16x8* drow = dy + (long)row * per_row;
+        for (int i = threadIdx.x; i < per_row; i += 256) {
+            const int w = i / groups;
+            float f[8], d[8], o[8];
+            unpack8(yrow[i], f);
+            pool_gather_row8(d, dout, idx, g, r, w, cg, groups);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float gk = (f[k] * kc.scale[k] + kc.shift[k]) > 0.f ? d[k] : 0.f;
-            const float xhat = (f[k] - kc.mean[k]) * kc.invstd[k];
-            o[k] = kc.scale[k] * (gk - kc.c1[k] - xhat * kc.c2[k]);
+            for (int k = 0; k < 8; ++k) {
+                const float gk = (f[k] * kc.scale[k] + kc.shift[k]) > 0.f ? d[k] : 0.f;
+                const float xhat = (f[k] - kc.mean[k]) * kc.invstd[k];
+                o[k] = kc.scale[k] * (gk - kc.c1[k] - xhat * kc.c2[k]);
+            }
+            drow[i] = pack8(o);
         }
-        dy[i] = pack8(o);
     }
 }
 
@@ -1045,16 +1081,15 @@ int vc_ew_pack_dgrad_batched(const void* shadow, void* wd, const int* table, int
 
 int vc_ew_bn_bwd_reduce_pooled(const void* y, const void* dout, const uint8_t* idx, const float* params, float* sums,
                                const VcPoolGeom& g, hipStream_t s) {
-    int grid, rpb;
-    reduce_geometry((long)g.N * g.T * g.H * g.W, g.C, grid, rpb);
-    VC_LAUNCH(bn_bwd_reduce_pooled_kernel, dim3(grid), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)dout, idx, params,
-              sums, g, rpb);
+    const long total = (long)g.N * g.To * g.Ho * g.Wo * (g.C / 8);
+    VC_LAUNCH(bn_bwd_reduce_pooled_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, s, (const bf16*)y,
+              (const bf16x8*)dout, idx, params, sums, g);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_bwd_apply_pooled(const void* y, const void* dout, const uint8_t* idx, const float* params, const float* coef,
                               void* dy, const VcPoolGeom& g, hipStream_t s) {
-    const long n8 = (long)g.N * g.T * g.H * g.W * (g.C / 8);
-    VC_LAUNCH(bn_bwd_apply_pooled_kernel, dim3(grid_for(n8)), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)dout, idx,
-              params, coef, (bf16x8*)dy, g);
+    const int nrows = g.N * g.T * g.H;
+    VC_LAUNCH(bn_bwd_apply_pooled_kernel, dim3(nrows < 4096 ? nrows : 4096), dim3(256), 0, s, (const bf16x8*)y,
+              (const bf16x8*)dout, idx, params, coef, (bf16x8*)dy, g);
     return VC_CHECK_LAUNCH();
 }

@@ -369,8 +369,12 @@ class R3DEngine:
         if self.trace is not None:  # tests look at the materialised pool-input gradient as well
             din = ops.maxpool3d_bwd(pd, g, idx)
             self._t("conv1", dpooled=g, dz=din)
-        dy0 = ops.bn_bwd_pooled(pd, y0, g, idx, p0, st.Co, self.gview(st.bn.weight), self.gview(st.bn.bias),
-                                sums=sums_pool.take(st.Co))
+        if all(k <= 2 * s for k, s in zip(self.pool[0], self.pool[1])):
+            dy0 = ops.bn_bwd_pooled(pd, y0, g, idx, p0, st.Co, self.gview(st.bn.weight), self.gview(st.bn.bias),
+                                    sums=sums_pool.take(st.Co))
+        else:  # windows overlapping more than twice per axis: materialise the pool-input gradient
+            dy0, _ = ops.bn_bwd(y0, ops.maxpool3d_bwd(pd, g, idx), p0, st.Co, self.gview(st.bn.weight),
+                                self.gview(st.bn.bias), mask=2, sums=sums_pool.take(st.Co))
         self._ready(st.bn.weight, st.bn.bias)
         if self._stem_scratch is None or self._stem_scratch.device != dev or self._stem_scratch.shape[0] != st.Co:
             self._stem_scratch = torch.zeros(st.Co, ops.STEM_K, dtype=F32, device=dev)
