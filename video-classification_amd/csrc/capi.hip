@@ -2,6 +2,7 @@
 // host, build the gather descriptions and launch.  Nothing here allocates or synchronises.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/vc3d.h"
@@ -56,6 +57,9 @@ static int conv_check(const vc_conv3d_desc* d, int& To, int& Ho, int& Wo) {
     return 0;
 }
 
+static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const void* w, void* out, float* stats,
+                    int accumulate, void* workspace, size_t ws_bytes, void* stream);
+
 extern "C" {
 
 const char* vc_last_error(void) { return g_err; }
@@ -72,6 +76,41 @@ int vc_conv3d_out_dims(const vc_conv3d_desc* d, int32_t* To, int32_t* Ho, int32_
 }
 
 static int fwd_nchunks(const vc_conv3d_desc* d) { return d->kt * d->kh * d->kw * (d->Ci / 64); }
+
+// stride 1, "same" padding, more than one tap, every tap within one plane / row / column of the output
+// position: served by the halo kernel (halo_conv.hip)
+static bool halo_ok(const vc_conv3d_desc* d) {
+    static const bool off = getenv("VC_NO_HALO") != nullptr;
+    if (off) return false;
+    if (d->st != 1 || d->sh != 1 || d->sw != 1) return false;
+    if (d->kt * d->kh * d->kw < 2) return false;
+    if (d->kt != 2 * d->pt + 1 || d->kh != 2 * d->ph + 1 || d->kw != 2 * d->pw + 1) return false;
+    if (d->kt > 3 || d->kh > 3 || d->kw > 3) return false;
+    return true;
+}
+static int halo_plan(const vc_conv3d_desc* d, bool dgrad, VcHaloPlan* plan) {
+    return vc_halo_plan(d->N * d->Ti, d->Hi, d->Wi, dgrad ? d->Co : d->Ci, dgrad ? d->Ci : d->Co, d->kt * d->kh * d->kw,
+                        plan);
+}
+static void halo_fill(VcHaloParams& p, const vc_conv3d_desc* d, bool dgrad) {
+    memset(&p, 0, sizeof(p));
+    p.NP = d->N * d->Ti, p.T = d->Ti, p.H = d->Hi, p.W = d->Wi;
+    p.Cs = dgrad ? d->Co : d->Ci;
+    p.Cn = dgrad ? d->Ci : d->Co;
+    p.ntaps = d->kt * d->kh * d->kw;
+    p.Kw = p.ntaps * p.Cs;
+    int i = 0;
+    for (int a = 0; a < d->kt; ++a)
+        for (int b = 0; b < d->kh; ++b)
+            for (int c = 0; c < d->kw; ++c, ++i) {
+                VcTap& t = p.taps[i];
+                // forward: source = out + (a - p); data gradient: source (in dy) = in + (p - a)
+                t.ot = (short)(dgrad ? d->pt - a : a - d->pt);
+                t.oh = (short)(dgrad ? d->ph - b : b - d->ph);
+                t.ow = (short)(dgrad ? d->pw - c : c - d->pw);
+                t.wk_off = i * p.Cs;
+            }
+}
 
 // largest tap count over the stride-parity classes of the data gradient
 static int dgrad_max_taps(const vc_conv3d_desc* d, bool* has_empty_class) {
@@ -106,6 +145,12 @@ static int dgrad_splits(const vc_conv3d_desc* d) {
 size_t vc_conv3d_workspace_bytes(const vc_conv3d_desc* d, int32_t op) {
     int To, Ho, Wo;
     if (conv_check(d, To, Ho, Wo)) return 0;
+    if ((op == 0 || op == 1) && halo_ok(d)) {
+        VcHaloPlan plan;
+        if (halo_plan(d, op == 1, &plan)) return 0;
+        const size_t out_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * (op == 1 ? d->Ci : d->Co);
+        return plan.splits > 1 ? (size_t)plan.splits * out_e * 4 : 0;
+    }
     if (op == 0) {
         const int s = vc_igemm_splits(d->N * To * Ho * Wo, d->Co, fwd_nchunks(d));
         return s > 1 ? (size_t)s * d->N * To * Ho * Wo * d->Co * 4 : 0;
@@ -129,6 +174,7 @@ int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(x && w && y, "conv3d_fwd: null pointer");
+    if (halo_ok(d)) return halo_run(d, false, x, w, y, bn_stats, 0, workspace, ws_bytes, stream);
     VcIgemmParams p;
     memset(&p, 0, sizeof(p));
     p.src = (const bf16*)x;
@@ -169,6 +215,39 @@ int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y
     return vc_launch_igemm(p, 0, S(stream));
 }
 
+}  // extern "C"
+
+static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const void* w, void* out, float* stats,
+                    int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+    VcHaloPlan plan;
+    if (halo_plan(d, dgrad, &plan)) {
+        vc_set_error("conv3d: no halo tiling fits (H=%d W=%d)", d->Hi, d->Wi);
+        return -2;
+    }
+    VcHaloParams p;
+    halo_fill(p, d, dgrad);
+    p.src = (const bf16*)src, p.wgt = (const bf16*)w, p.out = (bf16*)out;
+    p.stats = stats;
+    p.accumulate = accumulate;
+    const size_t out_e = (size_t)p.NP * p.H * p.W * p.Cn;
+    const int nchunks = p.Cs / 64;
+    if (plan.splits > 1 && (workspace == nullptr || ws_bytes < (size_t)plan.splits * out_e * 4)) plan.splits = 1;
+    if (plan.splits > 1) {
+        p.splits = plan.splits;
+        p.cps = (nchunks + plan.splits - 1) / plan.splits;
+        p.partial = (float*)workspace;
+        p.partial_stride = (long long)out_e;
+        p.stats = nullptr;
+        int rc = vc_launch_halo(p, plan, S(stream));
+        if (rc) return rc;
+        return vc_ew_splitk_finalize(p.partial, plan.splits, p.partial_stride, out, accumulate, stats,
+                                     (long)(out_e / p.Cn), p.Cn, S(stream));
+    }
+    return vc_launch_halo(p, plan, S(stream));
+}
+
+extern "C" {
+
 static inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 static inline int posmod(int a, int b) { return ((a % b) + b) % b; }
 
@@ -178,6 +257,7 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(dy && w_dgrad && dx, "conv3d_dgrad: null pointer");
+    if (halo_ok(d)) return halo_run(d, true, dy, w_dgrad, dx, nullptr, accumulate, workspace, ws_bytes, stream);
     const int ntaps_all = d->kt * d->kh * d->kw;
     const size_t dx_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
     int splits = dgrad_splits(d);

@@ -1,0 +1,488 @@
+// Stride-1 Conv3d forward / data-gradient with the activation HALO kept in LDS (gfx950).
+//
+// The tap-gather implicit GEMM of igemm_conv.hip re-fetches every activation row once per tap
+// (27x for 3x3x3): with Co = 64 per tile that is 64-80 bytes of global->LDS traffic per MFMA
+// clock per CU against a measured fill rate of ~18, so it tops out near 22 % of the MFMA peak.
+// Here a workgroup loads the activation rows its tile needs ONCE per 64-channel chunk -- TT
+// consecutive (n,t) planes x SEG consecutive (h,w) rows, plus one plane and W+1 rows of halo on
+// each side -- and walks the taps over that LDS image: a tap is a constant row shift
+// (dt*HR + dh*W + dw), applied when the B fragments are read.  Rows of the image that a tap must
+// not see (outside the sample: zero padding) are redirected per lane to a 128-byte zero row, from a
+// 27-bit validity mask computed once per output position.  Only the 8 KiB weight tiles stream in
+// during the tap loop: LDS-DMA into a 3-deep ring, two taps ahead of the MFMAs, retired with a counted
+// s_waitcnt vmcnt(N) and a raw s_barrier (a __syncthreads would drain the DMA queue every tap; an
+// LDS-DMA takes about 1 us to land under load, twice the MFMA time of a tap).
+//
+// GEMM view per tap:  D[co][m] += W_tap[co][ci] * X[m + shift(tap)][ci]
+//   tile   : 64 co x (NW*64) position slots; wave w owns slots [64w, 64w+64): 4x4 accumulators of
+//            v_mfma_f32_16x16x32_bf16, as in igemm_conv.hip (weights = A operand, so a lane ends
+//            with 4 consecutive channels of one position: an 8-byte channels-last store)
+//   slot p : plane tp = p / SEG, row s = p % SEG of the tile; slots >= TT*SEG are idle
+//   LDS    : [W buf 0 | W buf 1 | zero row | halo image], 128-byte rows, 16-byte slots XOR-swizzled
+//            by (row >> 1) & 7 on the DMA source side so that ds_read_b128 is conflict free
+// Dgrad of a stride-1 conv is the same kernel with the mirrored tap table and [Ci][taps*Co] weights.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int ROWB = 128;             // bytes per LDS row (64 bf16 channels)
+constexpr int WBUF = 64 * ROWB;       // one weight tile: 64 co x 64 ci
+constexpr int NWB = 3;                // weight tiles in the ring: the DMA runs 2 taps ahead of the MFMAs
+constexpr int ZERO_OFF = NWB * WBUF;  // 256 bytes reserved, first 128 are the zero row
+constexpr int HALO_OFF = NWB * WBUF + 256;
+
+__device__ __attribute__((aligned(128))) unsigned int vc_halo_zero_page[32];
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15), result in every lane: full-rate VALU, no LDS
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+    return v;
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void halo_conv_kernel(const VcHaloParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15;
+    const int lg = lane >> 4;
+
+    // ---- tile coordinates
+    const int tg = blockIdx.x / p.nseg;
+    const int sg = blockIdx.x - tg * p.nseg;
+    const int P0 = tg * p.TT;          // first (n,t) plane of the tile
+    const int s0 = sg * p.SEG;         // first (h,w) row of the tile inside a plane
+    const int co0 = blockIdx.y * 64;
+    const int HW = p.H * p.W;
+
+    if (tid < 32) ((unsigned*)(smem + ZERO_OFF))[tid] = 0u;
+    // the tap table lives in two VGPRs (lane i = tap i) and is read with v_readlane: no scalar-memory
+    // round trip (and no lgkmcnt(0) drain) per tap inside the loops
+    const int tv_shift = p.taps[lane & 31].src_off;
+    const int tv_wk = p.taps[lane & 31].wk_off;
+    const int tv_off = ((int)p.taps[lane & 31].ot & 0xff) | (((int)p.taps[lane & 31].oh & 0xff) << 8) |
+                       (((int)p.taps[lane & 31].ow & 0xff) << 16);
+#define VC_STAMP(k)                                                                                          \
+    do {                                                                                                     \
+        if (p.dbg != nullptr && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0)                              \
+            p.dbg[(size_t)blockIdx.x * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime();                   \
+    } while (0)
+    VC_STAMP(0);
+
+    // ---- per-lane output slots: 4 positions (b = 0..3), row = wave*64 + b*16 + l15
+    int lrow0[4];        // LDS image row of the slot's own position (tap 0,0,0)
+    unsigned mask[4];    // bit i: tap i reads inside the sample
+    int ooff[4];         // element offset of the output row, -1 = idle slot
+    int pt_[4], ph_[4], pw_[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int slot = wave * 64 + b * 16 + l15;
+        const int tp = (int)vc_div((unsigned)slot, p.dSEG);
+        const int s = slot - tp * p.SEG;
+        const int P = P0 + tp;
+        const int hw = s0 + s;
+        const bool ok = tp < p.TT && P < p.NP && hw < HW;
+        lrow0[b] = ok ? (tp + 1) * p.HR + s + p.W + 1 : p.HR + p.W + 1;  // idle slot: any in-image row, all taps masked
+        const int n = (int)vc_div((unsigned)P, p.dT);
+        const int h = (int)vc_div((unsigned)hw, p.dW);
+        pt_[b] = ok ? P - n * p.T : -4;  // -4: every tap falls outside
+        ph_[b] = h;
+        pw_[b] = hw - h * p.W;
+        ooff[b] = ok ? (P * HW + hw) * p.Cn : -1;
+        mask[b] = 0;
+    }
+    if (p.canon != 0) {
+        // canonical 3x3x3 table (tap i = (a*3 + b)*3 + c with offsets a-1, b-1, c-1, or all negated):
+        // the 27-bit mask is the outer product of three 3-bit per-axis validity masks
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            unsigned vt = 0, vh = 0, vw = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int o = p.canon > 0 ? k - 1 : 1 - k;
+                vt |= ((unsigned)(pt_[b] + o) < (unsigned)p.T) ? (1u << k) : 0u;
+                vh |= ((unsigned)(ph_[b] + o) < (unsigned)p.H) ? (1u << k) : 0u;
+                vw |= ((unsigned)(pw_[b] + o) < (unsigned)p.W) ? (1u << k) : 0u;
+            }
+            const unsigned hw9 = ((vh & 1u) ? vw : 0u) | ((vh & 2u) ? vw << 3 : 0u) | ((vh & 4u) ? vw << 6 : 0u);
+            mask[b] = ((vt & 1u) ? hw9 : 0u) | ((vt & 2u) ? hw9 << 9 : 0u) | ((vt & 4u) ? hw9 << 18 : 0u);
+        }
+    } else {
+        for (int i = 0; i < p.ntaps; ++i) {
+            const int o3 = __builtin_amdgcn_readlane(tv_off, i);
+            const int ot = (int)(signed char)(o3 & 0xff), oh = (int)(signed char)((o3 >> 8) & 0xff),
+                      ow = (int)(signed char)((o3 >> 16) & 0xff);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bool in = (unsigned)(pt_[b] + ot) < (unsigned)p.T && (unsigned)(ph_[b] + oh) < (unsigned)p.H &&
+                                (unsigned)(pw_[b] + ow) < (unsigned)p.W;
+                mask[b] |= in ? (1u << i) : 0u;
+            }
+        }
+    }
+
+    // ---- loader roles
+    // weight tile: 8 pieces of 8 rows x 128 B; wave w issues pieces w, w+NW, ...
+    const int prow = lane >> 3;   // row inside a piece
+    const int pslot = lane & 7;   // physical 16-B slot written by this lane
+    const gptr_t zero = (gptr_t)vc_halo_zero_page;
+    const long Mtot = (long)p.NP * HW;
+    const long gplane0 = (long)(P0 - 1) * HW + s0 - (p.W + 1);  // global row of image row 0
+
+    auto issue_w = [&](int tap, int cch, int buf) {
+        char* dst = smem + buf * WBUF;
+        for (int pc = wave; pc < 8; pc += NW) {
+            const int r = pc * 8 + prow;
+            const int ls = pslot ^ ((r >> 1) & 7);
+            const bf16* src = p.wgt + ((size_t)(co0 + r) * p.Kw + __builtin_amdgcn_readlane(tv_wk, tap) + cch * 64 + ls * 8);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + pc * 8 * ROWB), 16, 0, 0);
+        }
+    };
+    auto issue_halo = [&](int cch) {
+        char* dst = smem + HALO_OFF;
+        // image row r = q*HR + u  ->  global row gplane0 + q*HW + u
+        int r = wave * 8 + prow;
+        int q = r / p.HR;
+        int u = r - q * p.HR;
+        for (int pc = wave; pc < p.npieces; pc += NW) {
+            const long grow = gplane0 + (long)q * HW + u;
+            const int ls = pslot ^ ((r >> 1) & 7);
+            const bool ok = grow >= 0 && grow < Mtot && r < p.halo_rows;
+            const gptr_t src = ok ? (gptr_t)(p.src + (grow * p.Cs + cch * 64 + ls * 8)) : zero;
+            __builtin_amdgcn_global_load_lds(src, (lptr_t)(dst + pc * 8 * ROWB), 16, 0, 0);
+            r += NW * 8;
+            u += NW * 8;
+            while (u >= p.HR) {
+                u -= p.HR;
+                ++q;
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    VC_STAMP(1);
+
+    const int nchunks = p.Cs >> 6;
+    int cbeg = 0, cend = nchunks;
+    if (p.splits > 1) {
+        cbeg = blockIdx.z * p.cps;
+        cend = min(nchunks, cbeg + p.cps);
+    }
+    const int aswz = (l15 >> 1) & 7;  // == ((a*16 + l15) >> 1) & 7
+    const unsigned halo_base = HALO_OFF;
+
+    constexpr int WPT = (8 + NW - 1) / NW;  // weight DMA instructions per wave per tap
+
+    // fragments of one tap: 2 k-steps x (4 weight + 4 activation) ds_read_b128
+    auto load_frags = [&](int tap, bf16x8 (&fa)[2][4], bf16x8 (&fb)[2][4]) {
+        const char* sW = smem + (tap % NWB) * WBUF;
+        const int shift = __builtin_amdgcn_readlane(tv_shift, tap);  // row shift of this tap inside the image
+        unsigned baddr[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int lrow = lrow0[b] + shift;
+            const unsigned a_in = halo_base + (unsigned)lrow * ROWB + ((unsigned)(lg ^ ((lrow >> 1) & 7)) << 4);
+            const unsigned a_zero = ZERO_OFF + ((unsigned)lg << 4);
+            baddr[b] = ((mask[b] >> tap) & 1u) ? a_in : a_zero;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                fa[ks][a] = *(const bf16x8*)(sW + (a * 16 + l15) * ROWB + ((((ks << 2) + lg) ^ aswz) << 4));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[ks][b] = *(const bf16x8*)(smem + (baddr[b] ^ (unsigned)(ks << 6)));
+        }
+    };
+    auto mfma_all = [&](const bf16x8 (&fa)[2][4], const bf16x8 (&fb)[2][4]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][a], fb[ks][b], acc[a][b], 0, 0, 0);
+    };
+    // W[t] has landed (for this wave) once at most the instructions of the younger tiles are in flight;
+    // `younger` = how many of W[t+1], W[t+2] have been issued.  All LDS reads of this wave are retired too,
+    // so after the barrier the buffer they came from may be overwritten.
+    auto wait_w = [&](int younger) {
+        if (younger >= 2) {
+            if (WPT == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        } else if (younger == 1) {
+            if (WPT == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // one pipeline stage (t + 1 < ntaps): make W[t+1] visible, refill the ring, then fetch the fragments of
+    // tap t+1 into `nfa/nfb` WHILE the MFMAs of tap t run from `cfa/cfb`.  The reads are interleaved with
+    // the MFMAs in program order (2 ds_read_b128 per 4 MFMAs): issued all up front, the 16 reads would
+    // overflow the 4-bit lgkmcnt and the compiler would have to drain them before the first MFMA.
+    auto stage = [&](int t, int cch, bf16x8 (&cfa)[2][4], bf16x8 (&cfb)[2][4], bf16x8 (&nfa)[2][4],
+                     bf16x8 (&nfb)[2][4]) {
+        wait_w(t + 2 < p.ntaps ? 1 : 0);  // issued so far: up to W[t+2]
+        if (t + 3 < p.ntaps) issue_w(t + 3, cch, (t + 3) % NWB);  // overwrites W[t]: its reads are retired
+        load_frags(t + 1, nfa, nfb);
+        mfma_all(cfa, cfb);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMAs
+        }
+    };
+
+    for (int cch = cbeg; cch < cend; ++cch) {
+        if (cch != cbeg) __syncthreads();  // every wave is done with the previous chunk's image and weights
+        issue_halo(cch);
+        issue_w(0, cch, 0);
+        if (p.ntaps > 1) issue_w(1, cch, 1);
+        if (p.ntaps > 2) issue_w(2, cch, 2);
+        VC_STAMP(2);
+        wait_w(p.ntaps > 2 ? 2 : (p.ntaps > 1 ? 1 : 0));
+        VC_STAMP(3);
+        bf16x8 fa0[2][4], fb0[2][4], fa1[2][4], fb1[2][4];
+        load_frags(0, fa0, fb0);
+        int tap = 0;
+        for (; tap + 2 < p.ntaps; tap += 2) {
+            stage(tap, cch, fa0, fb0, fa1, fb1);
+            stage(tap + 1, cch, fa1, fb1, fa0, fb0);
+        }
+        if (tap + 1 < p.ntaps) {
+            stage(tap, cch, fa0, fb0, fa1, fb1);
+            mfma_all(fa1, fb1);
+        } else {
+            mfma_all(fa0, fb0);
+        }
+        VC_STAMP(4);
+    }
+
+    // ---- epilogue: acc[a][b][j] = D[co = co0 + a*16 + lg*4 + j][slot = wave*64 + b*16 + l15]
+    VC_STAMP(5);
+    const int cobase = co0 + lg * 4;
+    if (p.partial != nullptr) {
+        float* slab = p.partial + (size_t)blockIdx.z * p.partial_stride;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (ooff[b] < 0) continue;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) *(f32x4*)(slab + (size_t)ooff[b] + cobase + a * 16) = acc[a][b];
+        }
+        return;
+    }
+    __syncthreads();  // every wave has left the tap loop: the image area is free
+    // The image area is reused: [NW][64 positions][64 co] bf16 with a 144-byte row pitch for the output
+    // tile (so that it leaves as whole 128-byte channels-last rows, 16 bytes per lane), then
+    // [NW][2][64] floats for the BatchNorm partial sums of the waves.
+    constexpr int OPITCH = 144;
+    char* otile = smem + HALO_OFF + wave * 64 * OPITCH;
+    float* sstat = (float*)(smem + HALO_OFF + NW * 64 * OPITCH);
+    int* sooff = (int*)(sstat + NW * 128);  // [NW][64] output offsets of the wave's slots
+    if (!p.accumulate) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 v = acc[a][b];
+                *(bf16x4*)(otile + (b * 16 + l15) * OPITCH + (a * 16 + lg * 4) * 2) =
+                    (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            }
+            if (lg == 0) sooff[wave * 64 + b * 16 + l15] = ooff[b];
+        }
+    }
+    if (p.stats != nullptr) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float v = ooff[b] >= 0 ? acc[a][b][j] : 0.f;
+                    ss += v;
+                    qq += v * v;
+                }
+                ss = row16_sum(ss);
+                qq = row16_sum(qq);
+                if (l15 == 0) {
+                    sstat[wave * 128 + a * 16 + lg * 4 + j] = ss;
+                    sstat[wave * 128 + 64 + a * 16 + lg * 4 + j] = qq;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (p.stats != nullptr && tid < 128) {  // one atomic per channel and moment per workgroup
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += sstat[w * 128 + tid];
+        float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
+        atomicAdd(srep + (tid < 64 ? 0 : p.Cn) + co0 + (tid & 63), s);
+    }
+    if (!p.accumulate) {
+        // each wave streams its own 64 x 64 tile: 8 rows of 128 bytes per instruction
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = i * 8 + (lane >> 3);
+            const int oo = sooff[wave * 64 + r];
+            if (oo >= 0) {
+                const bf16x8 v = *(const bf16x8*)(otile + r * OPITCH + (lane & 7) * 16);
+                *(bf16x8*)(p.out + (size_t)oo + co0 + (lane & 7) * 8) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (ooff[b] < 0) continue;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                bf16* dst = p.out + (size_t)ooff[b] + cobase + a * 16;
+                f32x4 v = acc[a][b];
+                const bf16x4 old = *(const bf16x4*)dst;
+                v[0] += bf2f(old[0]);
+                v[1] += bf2f(old[1]);
+                v[2] += bf2f(old[2]);
+                v[3] += bf2f(old[3]);
+                *(bf16x4*)dst = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            }
+        }
+    }
+    VC_STAMP(6);
+}
+
+template <int NW>
+int launch_halo(const VcHaloParams& p, hipStream_t stream) {
+    int lds = HALO_OFF + p.npieces * 8 * ROWB;
+    const int epi = HALO_OFF + NW * 64 * 144 + NW * 128 * 4 + NW * 64 * 4;
+    if (lds < epi) lds = epi;
+    static bool attr_set[64] = {false};  // per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)halo_conv_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[dev] = true;
+    }
+    dim3 grid(p.ntg * p.nseg, p.Cn / 64, p.splits > 1 ? p.splits : 1);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((halo_conv_kernel<NW>), grid, dim3(NW * 64), lds, stream, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        vc_set_error("halo conv launch failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// Tile planning: NW waves (4 or 8), TT planes x SEG rows per tile, split-K over 64-channel chunks.
+// Cost model (MFMA clocks per CU): a workgroup spends 27*cps*512*(NW/4) on MFMAs and ~5 clocks per
+// halo row per chunk on the fill; workgroups run in rounds of (CUs x workgroups per CU).
+int vc_halo_plan(int NP, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* plan) {
+    const int HW = H * W;
+    const int nchunks = Cs / 64;
+    const char* env = getenv("VC_HALO_FORCE");  // "NW,TT,SEG,splits" for experiments
+    double best = 1e30;
+    VcHaloPlan bp;
+    bp.NW = 0;
+    for (int NW = 4; NW <= 8; NW += 4) {
+        const int BM = NW * 64;
+        for (int SEG = 1; SEG <= (HW < BM ? HW : BM); ++SEG) {
+            // segments that are whole (h) rows, whole planes, or an even split of a plane
+            if (!(SEG == HW || SEG % W == 0 || HW % SEG == 0)) continue;
+            int TT = BM / SEG;
+            if (TT > NP) TT = NP;
+            if (TT < 1) continue;
+            const int HR = SEG + 2 * W + 2;
+            const int rows = (TT + 2) * HR;
+            const int npieces = (rows + 7) / 8;
+            const int lds = HALO_OFF + npieces * 8 * ROWB;
+            if (lds > 160 * 1024) continue;
+            const int wg_per_cu = (160 * 1024) / lds >= 2 && NW == 4 ? 2 : 1;
+            const long tiles = (long)((NP + TT - 1) / TT) * ((HW + SEG - 1) / SEG);
+            for (int splits = 1; splits <= nchunks; splits *= 2) {
+                const int cps = (nchunks + splits - 1) / splits;
+                const long wgs = tiles * (Cn / 64) * splits;
+                const long rounds = (wgs + 256L * wg_per_cu - 1) / (256L * wg_per_cu);
+                const double mfma = (double)ntaps * cps * 512.0 * (NW / 4) * wg_per_cu;
+                const double fill = 5.0 * rows * cps * wg_per_cu * 0.7 + 3000.0;
+                double cost = rounds * (mfma * 1.15 + fill);
+                if (splits > 1) cost += 1.5e-3 * (double)NP * HW * Cn * splits / 256.0 + 4000.0;  // slabs + finalize
+                if (cost < best) {
+                    best = cost;
+                    bp.NW = NW, bp.TT = TT, bp.SEG = SEG, bp.splits = splits;
+                }
+            }
+        }
+    }
+    if (env) {
+        int a, b, c, d;
+        if (sscanf(env, "%d,%d,%d,%d", &a, &b, &c, &d) == 4 && (a == 4 || a == 8) && b >= 1 && c >= 1 && d >= 1 &&
+            b * c <= a * 64 && d <= nchunks)
+            bp.NW = a, bp.TT = b, bp.SEG = c, bp.splits = d;
+    }
+    if (bp.NW == 0) return -1;
+    *plan = bp;
+    return 0;
+}
+
+static long long* g_halo_dbg = nullptr;
+extern "C" void vc_debug_halo_stamps(long long* buf) { g_halo_dbg = buf; }  // tuning aid: per-workgroup s_memtime stamps
+
+int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream) {
+    p.dbg = g_halo_dbg;
+    if (p.Cs % 64 != 0 || p.Cn % 64 != 0 || p.ntaps < 1 || p.ntaps > 32) {
+        vc_set_error("halo conv: bad channels/taps (Cs=%d Cn=%d taps=%d)", p.Cs, p.Cn, p.ntaps);
+        return -2;
+    }
+    const int HW = p.H * p.W;
+    p.TT = plan.TT, p.SEG = plan.SEG;
+    p.HR = p.SEG + 2 * p.W + 2;
+    p.halo_rows = (p.TT + 2) * p.HR;
+    p.npieces = (p.halo_rows + 7) / 8;
+    p.dSEG = vc_make_fastdiv(p.SEG), p.dT = vc_make_fastdiv(p.T), p.dW = vc_make_fastdiv(p.W);
+    p.canon = 0;
+    if (p.ntaps == 27) {
+        bool fwd = true, rev = true;
+        for (int i = 0; i < 27; ++i) {
+            const int a = i / 9 - 1, b = (i / 3) % 3 - 1, c = i % 3 - 1;
+            fwd = fwd && p.taps[i].ot == a && p.taps[i].oh == b && p.taps[i].ow == c;
+            rev = rev && p.taps[i].ot == -a && p.taps[i].oh == -b && p.taps[i].ow == -c;
+        }
+        p.canon = fwd ? 1 : (rev ? -1 : 0);
+    }
+    p.ntg = (p.NP + p.TT - 1) / p.TT;
+    p.nseg = (HW + p.SEG - 1) / p.SEG;
+    if (p.TT * p.SEG > plan.NW * 64 || HALO_OFF + p.npieces * 8 * ROWB > 160 * 1024) {
+        vc_set_error("halo conv: plan does not fit (TT=%d SEG=%d NW=%d)", p.TT, p.SEG, plan.NW);
+        return -2;
+    }
+    for (int i = 0; i < p.ntaps; ++i) {  // a tap must stay inside the halo: one plane, one row, one column
+        const VcTap& t = p.taps[i];
+        if (t.ot < -1 || t.ot > 1 || t.oh < -1 || t.oh > 1 || t.ow < -1 || t.ow > 1) {
+            vc_set_error("halo conv: tap offset outside the 1-deep halo");
+            return -2;
+        }
+        p.taps[i].src_off = t.ot * p.HR + t.oh * p.W + t.ow;
+    }
+    return plan.NW == 8 ? launch_halo<8>(p, stream) : launch_halo<4>(p, stream);
+}

@@ -38,6 +38,30 @@ struct VcWgradParams {
     VcTap taps[32];
 };
 
+// halo_conv.hip: stride-1 conv with the activation halo resident in LDS
+struct VcHaloParams {
+    const bf16* src;  // [NP*H*W][Cs]
+    const bf16* wgt;  // [Cn][Kw]
+    bf16* out;        // [NP*H*W][Cn]
+    float* stats;     // nullable: [VC_STAT_REPLICAS][2][Cn]
+    int NP, T, H, W;  // NP = N*T planes of H*W rows
+    int Cs, Cn, Kw, ntaps;
+    int TT, SEG, HR, halo_rows, npieces, ntg, nseg;  // filled by vc_launch_halo from the plan
+    int canon;        // +1 / -1: canonical 3x3x3 tap order (forward / mirrored), 0: generic table
+    VcFastDiv dSEG, dT, dW;
+    int accumulate;
+    int splits, cps;
+    float* partial;
+    long long partial_stride;
+    long long* dbg;   // nullable: 8 s_memtime stamps per workgroup (tuning aid)
+    VcTap taps[32];   // ot/oh/ow in [-1,1]; src_off is rewritten to the row shift inside the LDS image
+};
+struct VcHaloPlan {
+    int NW, TT, SEG, splits;
+};
+int vc_halo_plan(int NP, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* plan);
+int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream);
+
 int vc_launch_igemm(const VcIgemmParams& p, int mode, hipStream_t stream);
 int vc_launch_wgrad(const VcWgradParams& p, int mode, hipStream_t stream);
 // split-K planning (shared by the workspace query and the launch)
