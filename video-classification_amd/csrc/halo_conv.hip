@@ -395,8 +395,11 @@ int launch_halo(const VcHaloParams& p, hipStream_t stream) {
 }  // namespace
 
 // Tile planning: NW waves (4 or 8), TT planes x SEG rows per tile, split-K over 64-channel chunks.
-// Cost model (MFMA clocks per CU): a workgroup spends 27*cps*512*(NW/4) on MFMAs and ~5 clocks per
-// halo row per chunk on the fill; workgroups run in rounds of (CUs x workgroups per CU).
+// Cost model in shader clocks per workgroup, constants measured on MI355X with per-phase s_memtime stamps
+// (scripts/halo_stamps.py): ~2k prologue, ~11.5 clocks per image row of fill (the chip-wide fill rate when
+// every CU loads its image at once), per tap and chunk ~1550 with two waves per SIMD (8 waves, or two
+// 4-wave workgroups per CU) and ~2500 for a lone 4-wave workgroup, ~7k epilogue; workgroups run in rounds
+// of (256 CUs x workgroups per CU); split-K adds the slab traffic and a finalize launch.
 int vc_halo_plan(int NP, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* plan) {
     const int HW = H * W;
     const int nchunks = Cs / 64;
@@ -415,18 +418,20 @@ int vc_halo_plan(int NP, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* pl
             const int HR = SEG + 2 * W + 2;
             const int rows = (TT + 2) * HR;
             const int npieces = (rows + 7) / 8;
-            const int lds = HALO_OFF + npieces * 8 * ROWB;
+            int lds = HALO_OFF + npieces * 8 * ROWB;
+            const int epi = HALO_OFF + NW * 64 * 144 + NW * 128 * 4 + NW * 64 * 4;
+            if (lds < epi) lds = epi;
             if (lds > 160 * 1024) continue;
-            const int wg_per_cu = (160 * 1024) / lds >= 2 && NW == 4 ? 2 : 1;
+            const int wgcu = (NW == 4 && 2 * lds <= 160 * 1024) ? 2 : 1;
             const long tiles = (long)((NP + TT - 1) / TT) * ((HW + SEG - 1) / SEG);
             for (int splits = 1; splits <= nchunks; splits *= 2) {
                 const int cps = (nchunks + splits - 1) / splits;
                 const long wgs = tiles * (Cn / 64) * splits;
-                const long rounds = (wgs + 256L * wg_per_cu - 1) / (256L * wg_per_cu);
-                const double mfma = (double)ntaps * cps * 512.0 * (NW / 4) * wg_per_cu;
-                const double fill = 5.0 * rows * cps * wg_per_cu * 0.7 + 3000.0;
-                double cost = rounds * (mfma * 1.15 + fill);
-                if (splits > 1) cost += 1.5e-3 * (double)NP * HW * Cn * splits / 256.0 + 4000.0;  // slabs + finalize
+                const long rounds = (wgs + 256L * wgcu - 1) / (256L * wgcu);
+                const double per_tap = NW == 8 ? 1550.0 : (wgcu == 2 ? 1700.0 : 2500.0);
+                const double t_wg = 2000.0 + 7000.0 + cps * (11.5 * rows + ntaps * per_tap);
+                double cost = rounds * t_wg * (wgcu == 2 ? 1.7 : 1.0);
+                if (splits > 1) cost += 15000.0 + 2.4e3 * ((double)NP * HW * Cn * 4.0 * (splits + 0.5)) / 4.0e6;  // slabs at ~4 TB/s
                 if (cost < best) {
                     best = cost;
                     bp.NW = NW, bp.TT = TT, bp.SEG = SEG, bp.splits = splits;
