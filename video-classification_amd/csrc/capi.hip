@@ -88,6 +88,12 @@ static bool halo_ok(const vc_conv3d_desc* d) {
     if (d->kt > 3 || d->kh > 3 || d->kw > 3) return false;
     return true;
 }
+// canonical 3x3x3 / stride 1 / pad 1: weight gradient by wgrad9_conv.hip
+static bool wgrad9_ok(const vc_conv3d_desc* d) {
+    static const bool off = getenv("VC_NO_WGRAD9") != nullptr;
+    return !off && d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 1 &&
+           d->ph == 1 && d->pw == 1;
+}
 static int halo_plan(const vc_conv3d_desc* d, bool dgrad, VcHaloPlan* plan) {
     return vc_halo_plan(d->N * d->Ti, d->Hi, d->Wi, dgrad ? d->Co : d->Ci, dgrad ? d->Ci : d->Co, d->kt * d->kh * d->kw,
                         plan);
@@ -158,6 +164,11 @@ size_t vc_conv3d_workspace_bytes(const vc_conv3d_desc* d, int32_t op) {
     if (op == 1) {
         const int s = dgrad_splits(d);
         return s > 1 ? (size_t)s * d->N * d->Ti * d->Hi * d->Wi * d->Ci * 4 : 0;
+    }
+    if (op == 2 && wgrad9_ok(d)) {
+        int rps;
+        const int s = vc_wgrad9_plan((long)d->N * d->Ti * d->Hi * d->Wi, d->Wi, d->Ci, d->Co, &rps);
+        if (s > 0) return s > 1 ? (size_t)s * d->Co * 27 * d->Ci * 4 : 0;
     }
     if (op == 2) {
         int rps;
@@ -345,6 +356,27 @@ int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, floa
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(x && dy && dw, "conv3d_wgrad: null pointer");
+    if (wgrad9_ok(d)) {
+        int rps9 = 0;
+        const int s9 = vc_wgrad9_plan((long)d->N * d->Ti * d->Hi * d->Wi, d->Wi, d->Ci, d->Co, &rps9);
+        if (s9 > 0) {
+            VcWgrad9Params q;
+            memset(&q, 0, sizeof(q));
+            q.x = (const bf16*)x, q.dy = (const bf16*)dy, q.dw = dw;
+            q.NP = d->N * d->Ti, q.T = d->Ti, q.H = d->Hi, q.W = d->Wi;
+            q.Cs = d->Ci, q.Co = d->Co, q.Kw = 27 * d->Ci;
+            q.rows_per_split = rps9, q.splits = s9;
+            const size_t dw_e9 = (size_t)d->Co * q.Kw;
+            if (s9 > 1 && workspace != nullptr && ws_bytes >= (size_t)s9 * dw_e9 * 4) {
+                q.partial = (float*)workspace;
+                q.partial_stride = (long long)dw_e9;
+                rc = vc_launch_wgrad9(q, S(stream));
+                if (rc) return rc;
+                return vc_ew_splitk_reduce_wgrad(q.partial, s9, q.partial_stride, dw, (long)dw_e9, S(stream));
+            }
+            return vc_launch_wgrad9(q, S(stream));  // no workspace: float atomics when split
+        }
+    }
     VcWgradParams p;
     memset(&p, 0, sizeof(p));
     p.x = (const bf16*)x;

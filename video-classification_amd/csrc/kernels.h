@@ -62,6 +62,21 @@ struct VcHaloPlan {
 int vc_halo_plan(int NP, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* plan);
 int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream);
 
+// wgrad9_conv.hip: 3x3x3 stride-1 weight gradient, nine (dh,dw) taps per LDS image
+struct VcWgrad9Params {
+    const bf16* x;   // [NP*H*W][Cs]
+    const bf16* dy;  // [NP*H*W][Co]
+    float* dw;       // [Co][27*Cs] fp32
+    float* partial;  // nullable: fp32 slabs [splits][Co][27*Cs]
+    long long partial_stride;
+    int NP, T, H, W, Cs, Co, Kw;
+    int rows_per_split, splits;
+    long long* dbg;  // nullable: per-workgroup phase clocks (tuning aid)
+    VcFastDiv dHW, dT, dW;
+};
+int vc_wgrad9_plan(long M, int W, int Cs, int Co, int* rows_per_split);  // splits; 0 = geometry not supported
+int vc_launch_wgrad9(VcWgrad9Params& p, hipStream_t stream);
+
 int vc_launch_igemm(const VcIgemmParams& p, int mode, hipStream_t stream);
 int vc_launch_wgrad(const VcWgradParams& p, int mode, hipStream_t stream);
 // split-K planning (shared by the workspace query and the launch)

@@ -12,6 +12,8 @@
 // Work split: blockIdx.x = group of NB 64-wide column blocks (each block = one tap x 64 ci),
 // blockIdx.y = BCO-wide co block, blockIdx.z = slice of m (split-K).  Partial sums are added
 // to the fp32 gradient with float atomics (the gradient buffer is zeroed by the caller).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -254,7 +256,8 @@ int vc_wgrad_splits(int M, int Co, int nblk, int* rows_per_split) {
     const int bco = wide ? 128 : 64;
     const long tiles = (long)((nblk + nb - 1) / nb) * (Co / bco);
     // aim for ~1024 workgroups, at least 4 chunks (256 rows) per split
-    long splits = (1024 + tiles - 1) / tiles;
+    static const long target = getenv("VC_WGRAD_TARGET") ? atol(getenv("VC_WGRAD_TARGET")) : 1024;
+    long splits = (target + tiles - 1) / tiles;
     const long maxsplits = (M + 255) / 256;
     if (splits > maxsplits) splits = maxsplits;
     if (splits < 1) splits = 1;
