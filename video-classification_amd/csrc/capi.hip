@@ -95,7 +95,7 @@ static bool wgrad9_ok(const vc_conv3d_desc* d) {
            d->ph == 1 && d->pw == 1;
 }
 static int halo_plan(const vc_conv3d_desc* d, bool dgrad, VcHaloPlan* plan) {
-    return vc_halo_plan(d->N * d->Ti, d->Hi, d->Wi, dgrad ? d->Co : d->Ci, dgrad ? d->Ci : d->Co, d->kt * d->kh * d->kw,
+    return vc_halo_plan(d->N * d->Ti, d->Ti, d->Hi, d->Wi, dgrad ? d->Co : d->Ci, dgrad ? d->Ci : d->Co, d->kt * d->kh * d->kw,
                         plan);
 }
 static void halo_fill(VcHaloParams& p, const vc_conv3d_desc* d, bool dgrad) {
@@ -241,7 +241,7 @@ static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const 
     p.stats = stats;
     p.accumulate = accumulate;
     const size_t out_e = (size_t)p.NP * p.H * p.W * p.Cn;
-    const int nchunks = p.Cs / 64;
+    const int nchunks = p.Cs / plan.CK;
     if (plan.splits > 1 && (workspace == nullptr || ws_bytes < (size_t)plan.splits * out_e * 4)) plan.splits = 1;
     if (plan.splits > 1) {
         p.splits = plan.splits;

@@ -29,11 +29,24 @@
 
 namespace {
 
-constexpr int ROWB = 128;             // bytes per LDS row (64 bf16 channels)
-constexpr int WBUF = 64 * ROWB;       // one weight tile: 64 co x 64 ci
-constexpr int NWB = 3;                // weight tiles in the ring: the DMA runs 2 taps ahead of the MFMAs
-constexpr int ZERO_OFF = NWB * WBUF;  // 256 bytes reserved, first 128 are the zero row
-constexpr int HALO_OFF = NWB * WBUF + 256;
+constexpr int NWB = 3;  // weight tiles in the ring: the DMA runs 2 taps ahead of the MFMAs
+
+// CK = channels per K chunk (64 or 32).  CK = 32 halves the image and the weight tiles: two 4-wave
+// workgroups then fit in one CU's LDS and one loads / stores while the other runs its MFMAs.
+template <int CK>
+struct HaloCfg {
+    static constexpr int ROWB = CK * 2;         // bytes per LDS row
+    static constexpr int PR = 1024 / ROWB;      // rows per 1-KiB LDS-DMA piece (8 or 16)
+    static constexpr int SLOTS = ROWB / 16;     // 16-byte slots per row (8 or 4)
+    static constexpr int KS = CK / 32;          // MFMA k-steps per tap and chunk
+    static constexpr int WBUF = 64 * ROWB;      // one weight tile: 64 co x CK ci
+    static constexpr int WPIECES = WBUF / 1024; // 8 or 4
+    static constexpr int ZERO_OFF = NWB * WBUF; // 256 bytes reserved, the first ROWB are the zero row
+    static constexpr int HALO_OFF = NWB * WBUF + 256;
+    // XOR swizzle of the 16-byte slot by the row, so that the 16 rows a ds_read_b128 lane group touches
+    // fall into 16 different slots of the 256-byte bank row
+    static __device__ __host__ constexpr int swz(int row) { return CK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
+};
 
 __device__ __attribute__((aligned(128))) unsigned int vc_halo_zero_page[32];
 
@@ -49,8 +62,19 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int NW>
+#ifndef VC_HALO_ABLATE
+#define VC_HALO_ABLATE 0  // timing experiments only (scripts/halo_ablate.sh): 1 no tap barrier, 2 no image reads, 4 no weight reads, 8 no weight DMA, 16 no MFMA
+#endif
+
+// PAD: the LDS image is stored zero-padded -- (R + 2) x (W + 2) rows per plane, out-of-sample rows filled
+// from the zero page by the loader -- so a tap is a pure row shift: no validity masks, no per-tap selects
+// (the tap loop is VALU-issue bound otherwise).  Needs whole-h-row segments and TT | T.
+template <int NW, int CK, bool PAD>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void halo_conv_kernel(const VcHaloParams p) {
+    static_assert(!PAD || CK == 64, "the padded image form is built for 128-byte rows");
+    using Cfg = HaloCfg<CK>;
+    constexpr int ROWB = Cfg::ROWB, WBUF = Cfg::WBUF, ZERO_OFF = Cfg::ZERO_OFF, HALO_OFF = Cfg::HALO_OFF, PR = Cfg::PR,
+                  KS = Cfg::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -81,9 +105,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     VC_STAMP(0);
 
     // ---- per-lane output slots: 4 positions (b = 0..3), row = wave*64 + b*16 + l15
-    int lrow0[4];        // LDS image row of the slot's own position (tap 0,0,0)
-    unsigned mask[4];    // bit i: tap i reads inside the sample
+    int lrow0[4];        // LDS image row of the slot's own position (tap 0,0,0); PAD: its byte offset (row << 7)
+    unsigned mask[4];    // bit i: tap i reads inside the sample (unused with PAD)
     int ooff[4];         // element offset of the output row, -1 = idle slot
+    if constexpr (PAD) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int slot = wave * 64 + b * 16 + l15;
+            const int tp = (int)vc_div((unsigned)slot, p.dSEG);
+            const int s = slot - tp * p.SEG;
+            const int hl = (int)vc_div((unsigned)s, p.dW);
+            const int w = s - hl * p.W;
+            const int P = P0 + tp;
+            const bool ok = tp < p.TT && P < p.NP;
+            // idle slot: the tile's first position (every tap stays inside the image; the result is dropped)
+            lrow0[b] = (ok ? (tp + 1) * p.HR + (hl + 1) * p.Wp + (w + 1) : p.HR + p.Wp + 1) << 7;
+            ooff[b] = ok ? (P * HW + s0 + s) * p.Cn : -1;
+            mask[b] = 0;
+        }
+    } else {
     int pt_[4], ph_[4], pw_[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -131,41 +171,63 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         }
     }
+    }
 
     // ---- loader roles
     // weight tile: 8 pieces of 8 rows x 128 B; wave w issues pieces w, w+NW, ...
-    const int prow = lane >> 3;   // row inside a piece
-    const int pslot = lane & 7;   // physical 16-B slot written by this lane
+    const int prow = lane / Cfg::SLOTS;   // row inside a piece
+    const int pslot = lane % Cfg::SLOTS;  // physical 16-B slot written by this lane
     const gptr_t zero = (gptr_t)vc_halo_zero_page;
     const long Mtot = (long)p.NP * HW;
     const long gplane0 = (long)(P0 - 1) * HW + s0 - (p.W + 1);  // global row of image row 0
 
     auto issue_w = [&](int tap, int cch, int buf) {
         char* dst = smem + buf * WBUF;
-        for (int pc = wave; pc < 8; pc += NW) {
-            const int r = pc * 8 + prow;
-            const int ls = pslot ^ ((r >> 1) & 7);
-            const bf16* src = p.wgt + ((size_t)(co0 + r) * p.Kw + __builtin_amdgcn_readlane(tv_wk, tap) + cch * 64 + ls * 8);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + pc * 8 * ROWB), 16, 0, 0);
+        for (int pc = wave; pc < Cfg::WPIECES; pc += NW) {
+            const int r = pc * PR + prow;
+            const int ls = pslot ^ Cfg::swz(r);
+            const bf16* src = p.wgt + ((size_t)(co0 + r) * p.Kw + __builtin_amdgcn_readlane(tv_wk, tap) + cch * CK + ls * 8);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + pc * 1024), 16, 0, 0);
         }
     };
     auto issue_halo = [&](int cch) {
         char* dst = smem + HALO_OFF;
-        // image row r = q*HR + u  ->  global row gplane0 + q*HW + u
-        int r = wave * 8 + prow;
-        int q = r / p.HR;
-        int u = r - q * p.HR;
-        for (int pc = wave; pc < p.npieces; pc += NW) {
-            const long grow = gplane0 + (long)q * HW + u;
-            const int ls = pslot ^ ((r >> 1) & 7);
-            const bool ok = grow >= 0 && grow < Mtot && r < p.halo_rows;
-            const gptr_t src = ok ? (gptr_t)(p.src + (grow * p.Cs + cch * 64 + ls * 8)) : zero;
-            __builtin_amdgcn_global_load_lds(src, (lptr_t)(dst + pc * 8 * ROWB), 16, 0, 0);
-            r += NW * 8;
-            u += NW * 8;
-            while (u >= p.HR) {
-                u -= p.HR;
-                ++q;
+        if constexpr (PAD) {
+            // image row r = (q*(R+2) + hh)*(W+2) + ww  ->  plane P0-1+q, row h0-1+hh, column ww-1; zero outside
+            const int p0t = P0 - (int)vc_div((unsigned)P0, p.dT) * p.T;
+            const int h0 = sg * p.R;
+            for (int pc = wave; pc < p.npieces; pc += NW) {
+                const int r = pc * PR + prow;
+                const int q = (int)vc_div((unsigned)r, p.dHR);
+                const int u = r - q * p.HR;
+                const int hh = (int)vc_div((unsigned)u, p.dWp);
+                const int w = u - hh * p.Wp - 1;
+                const int h = h0 - 1 + hh;
+                const int P = P0 - 1 + q;
+                const bool ok = r < p.halo_rows && (q >= 1 || p0t != 0) && (q <= p.TT || p0t + p.TT != p.T) && P < p.NP &&
+                                (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                const long grow = (long)P * HW + h * p.W + w;
+                const int ls = pslot ^ Cfg::swz(r);
+                const gptr_t src = ok ? (gptr_t)(p.src + (grow * p.Cs + cch * CK + ls * 8)) : zero;
+                __builtin_amdgcn_global_load_lds(src, (lptr_t)(dst + pc * 1024), 16, 0, 0);
+            }
+        } else {
+            // image row r = q*HR + u  ->  global row gplane0 + q*HW + u
+            int r = wave * PR + prow;
+            int q = r / p.HR;
+            int u = r - q * p.HR;
+            for (int pc = wave; pc < p.npieces; pc += NW) {
+                const long grow = gplane0 + (long)q * HW + u;
+                const int ls = pslot ^ Cfg::swz(r);
+                const bool ok = grow >= 0 && grow < Mtot && r < p.halo_rows;
+                const gptr_t src = ok ? (gptr_t)(p.src + (grow * p.Cs + cch * CK + ls * 8)) : zero;
+                __builtin_amdgcn_global_load_lds(src, (lptr_t)(dst + pc * 1024), 16, 0, 0);
+                r += NW * PR;
+                u += NW * PR;
+                while (u >= p.HR) {
+                    u -= p.HR;
+                    ++q;
+                }
             }
         }
     };
@@ -177,51 +239,79 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     VC_STAMP(1);
 
-    const int nchunks = p.Cs >> 6;
+    const int nchunks = p.Cs / CK;
     int cbeg = 0, cend = nchunks;
     if (p.splits > 1) {
         cbeg = blockIdx.z * p.cps;
         cend = min(nchunks, cbeg + p.cps);
     }
-    const int aswz = (l15 >> 1) & 7;  // == ((a*16 + l15) >> 1) & 7
+    const int aswz = Cfg::swz(l15);  // == swz(a*16 + l15)
     const unsigned halo_base = HALO_OFF;
 
-    constexpr int WPT = (8 + NW - 1) / NW;  // weight DMA instructions per wave per tap
+    constexpr int WPT = (Cfg::WPIECES + NW - 1) / NW;  // weight DMA instructions per wave per tap
+    static_assert(Cfg::WPIECES % NW == 0 || Cfg::WPIECES < NW, "every wave must issue the same number of weight pieces");
 
     // fragments of one tap: 2 k-steps x (4 weight + 4 activation) ds_read_b128
-    auto load_frags = [&](int tap, bf16x8 (&fa)[2][4], bf16x8 (&fb)[2][4]) {
+    auto load_frags = [&](int tap, bf16x8 (&fa)[KS][4], bf16x8 (&fb)[KS][4]) {
         const char* sW = smem + (tap % NWB) * WBUF;
         const int shift = __builtin_amdgcn_readlane(tv_shift, tap);  // row shift of this tap inside the image
-        unsigned baddr[4];
+        unsigned baddr[KS][4];
+        if constexpr (PAD) {
+            // byte offset of the row L = (row << 7); its 16-byte slot is lg ^ ((row >> 1) & 7) (+4 for k-step 1)
+            const unsigned sh = (unsigned)shift << 7;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int lrow = lrow0[b] + shift;
-            const unsigned a_in = halo_base + (unsigned)lrow * ROWB + ((unsigned)(lg ^ ((lrow >> 1) & 7)) << 4);
-            const unsigned a_zero = ZERO_OFF + ((unsigned)lg << 4);
-            baddr[b] = ((mask[b] >> tap) & 1u) ? a_in : a_zero;
+            for (int b = 0; b < 4; ++b) {
+                const unsigned L = (unsigned)lrow0[b] + sh;
+                const unsigned sw = (L >> 4) & 0x70u;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) baddr[ks][b] = halo_base + ((sw ^ (unsigned)((lg << 4) ^ (ks << 6))) + L);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int lrow = lrow0[b] + shift;
+                const unsigned a_in = halo_base + (unsigned)lrow * ROWB + ((unsigned)(lg ^ Cfg::swz(lrow)) << 4);
+                const unsigned a_zero = ZERO_OFF + ((unsigned)lg << 4);
+                const unsigned a0 = ((mask[b] >> tap) & 1u) ? a_in : a_zero;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) baddr[ks][b] = a0 ^ (unsigned)(ks << 6);
+            }
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
+            if (!(VC_HALO_ABLATE & 4)) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-                fa[ks][a] = *(const bf16x8*)(sW + (a * 16 + l15) * ROWB + ((((ks << 2) + lg) ^ aswz) << 4));
+                for (int a = 0; a < 4; ++a)
+                    fa[ks][a] = *(const bf16x8*)(sW + (a * 16 + l15) * ROWB + ((((ks << 2) + lg) ^ aswz) << 4));
+            }
+            if (!(VC_HALO_ABLATE & 2)) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) fb[ks][b] = *(const bf16x8*)(smem + (baddr[b] ^ (unsigned)(ks << 6)));
+                for (int b = 0; b < 4; ++b) fb[ks][b] = *(const bf16x8*)(smem + baddr[ks][b]);
+            }
         }
     };
-    auto mfma_all = [&](const bf16x8 (&fa)[2][4], const bf16x8 (&fb)[2][4]) {
+    auto mfma_all = [&](const bf16x8 (&fa)[KS][4], const bf16x8 (&fb)[KS][4]) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][a], fb[ks][b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 4; ++b) {
+                    if (VC_HALO_ABLATE & 16) {
+                        asm volatile("" : "+v"(acc[a][b]) : "v"(fa[ks][a]), "v"(fb[ks][b]));
+                    } else {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][a], fb[ks][b], acc[a][b], 0, 0, 0);
+                    }
+                }
     };
     // W[t] has landed (for this wave) once at most the instructions of the younger tiles are in flight;
     // `younger` = how many of W[t+1], W[t+2] have been issued.  All LDS reads of this wave are retired too,
     // so after the barrier the buffer they came from may be overwritten.
+    // (__builtin_amdgcn_s_waitcnt rather than inline asm: the compiler's own wait-count pass sees the drain and
+    // does not add a second lgkmcnt(0) in front of the first MFMA of the stage.  imm = vmcnt[3:0] | expcnt 7 << 4
+    // | lgkmcnt << 8 | vmcnt[5:4] << 14; 0xF in a field = no wait.)
     auto wait_w = [&](int younger) {
+#if VC_HALO_ABLATE & 32
         if (younger >= 2) {
             if (WPT == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -233,19 +323,33 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        return;
+#endif
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), unconditionally (the vmcnt part below may sit in branches)
+        if (younger >= 2) {
+            if (WPT == 1) __builtin_amdgcn_s_waitcnt(0x0F72);  // vmcnt(2)
+            else __builtin_amdgcn_s_waitcnt(0x0F74);           // vmcnt(4)
+        } else if (younger == 1) {
+            if (WPT == 1) __builtin_amdgcn_s_waitcnt(0x0F71);  // vmcnt(1)
+            else __builtin_amdgcn_s_waitcnt(0x0F72);           // vmcnt(2)
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+        }
+        if (!(VC_HALO_ABLATE & 1)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
     // one pipeline stage (t + 1 < ntaps): make W[t+1] visible, refill the ring, then fetch the fragments of
     // tap t+1 into `nfa/nfb` WHILE the MFMAs of tap t run from `cfa/cfb`.  The reads are interleaved with
     // the MFMAs in program order (2 ds_read_b128 per 4 MFMAs): issued all up front, the 16 reads would
     // overflow the 4-bit lgkmcnt and the compiler would have to drain them before the first MFMA.
-    auto stage = [&](int t, int cch, bf16x8 (&cfa)[2][4], bf16x8 (&cfb)[2][4], bf16x8 (&nfa)[2][4],
-                     bf16x8 (&nfb)[2][4]) {
+    auto stage = [&](int t, int cch, bf16x8 (&cfa)[KS][4], bf16x8 (&cfb)[KS][4], bf16x8 (&nfa)[KS][4],
+                     bf16x8 (&nfb)[KS][4]) {
         wait_w(t + 2 < p.ntaps ? 1 : 0);  // issued so far: up to W[t+2]
-        if (t + 3 < p.ntaps) issue_w(t + 3, cch, (t + 3) % NWB);  // overwrites W[t]: its reads are retired
+        if (!(VC_HALO_ABLATE & 8) && t + 3 < p.ntaps) issue_w(t + 3, cch, (t + 3) % NWB);  // overwrites W[t]: its reads are retired
         load_frags(t + 1, nfa, nfb);
         mfma_all(cfa, cfb);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4 * KS; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMAs
         }
@@ -260,7 +364,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         VC_STAMP(2);
         wait_w(p.ntaps > 2 ? 2 : (p.ntaps > 1 ? 1 : 0));
         VC_STAMP(3);
-        bf16x8 fa0[2][4], fb0[2][4], fa1[2][4], fb1[2][4];
+        bf16x8 fa0[KS][4], fb0[KS][4], fa1[KS][4], fb1[KS][4];
         load_frags(0, fa0, fb0);
         int tap = 0;
         for (; tap + 2 < p.ntaps; tap += 2) {
@@ -369,21 +473,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     VC_STAMP(6);
 }
 
-template <int NW>
+// LDS bytes of a workgroup: ring + zero row + the larger of the image and the epilogue staging area
+template <int NW, int CK>
+constexpr int halo_lds_bytes(int npieces) {
+    const int img = HaloCfg<CK>::HALO_OFF + npieces * 1024;
+    const int epi = HaloCfg<CK>::HALO_OFF + NW * 64 * 144 + NW * 128 * 4 + NW * 64 * 4;
+    return img > epi ? img : epi;
+}
+static int halo_lds(int NW, int CK, int npieces) {
+    if (CK == 32) return NW == 8 ? halo_lds_bytes<8, 32>(npieces) : halo_lds_bytes<4, 32>(npieces);
+    return NW == 8 ? halo_lds_bytes<8, 64>(npieces) : halo_lds_bytes<4, 64>(npieces);
+}
+
+template <int NW, int CK, bool PAD>
 int launch_halo(const VcHaloParams& p, hipStream_t stream) {
-    int lds = HALO_OFF + p.npieces * 8 * ROWB;
-    const int epi = HALO_OFF + NW * 64 * 144 + NW * 128 * 4 + NW * 64 * 4;
-    if (lds < epi) lds = epi;
+    const int lds = halo_lds_bytes<NW, CK>(p.npieces);
     static bool attr_set[64] = {false};  // per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)halo_conv_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)halo_conv_kernel<NW, CK, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set[dev] = true;
     }
     dim3 grid(p.ntg * p.nseg, p.Cn / 64, p.splits > 1 ? p.splits : 1);
     (void)hipGetLastError();
-    hipLaunchKernelGGL((halo_conv_kernel<NW>), grid, dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((halo_conv_kernel<NW, CK, PAD>), grid, dim3(NW * 64), lds, stream, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         vc_set_error("halo conv launch failed: %s", hipGetErrorString(e));
@@ -400,52 +514,73 @@ int launch_halo(const VcHaloParams& p, hipStream_t stream) {
 // every CU loads its image at once), per tap and chunk ~1550 with two waves per SIMD (8 waves, or two
 // 4-wave workgroups per CU) and ~2500 for a lone 4-wave workgroup, ~7k epilogue; workgroups run in rounds
 // of (256 CUs x workgroups per CU); split-K adds the slab traffic and a finalize launch.
-int vc_halo_plan(int NP, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* plan) {
+static const double vc_halo_k2 = getenv("VC_HALO_K2") ? atof(getenv("VC_HALO_K2")) : 1.0;  // tuning knob of the 2-WG/CU model
+
+static const double vc_halo_kpad = getenv("VC_HALO_KPAD") ? atof(getenv("VC_HALO_KPAD")) : 1250.0;  // per-tap clocks, padded form
+
+int vc_halo_plan(int NP, int T, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* plan) {
     const int HW = H * W;
-    const int nchunks = Cs / 64;
-    const char* env = getenv("VC_HALO_FORCE");  // "NW,TT,SEG,splits" for experiments
+    const char* env = getenv("VC_HALO_FORCE");  // "NW,TT,SEG,splits[,CK[,pad]]" for experiments
+    static const bool no_pad = getenv("VC_HALO_NO_PAD") != nullptr;
     double best = 1e30;
     VcHaloPlan bp;
     bp.NW = 0;
-    for (int NW = 4; NW <= 8; NW += 4) {
-        const int BM = NW * 64;
-        for (int SEG = 1; SEG <= (HW < BM ? HW : BM); ++SEG) {
-            // segments that are whole (h) rows, whole planes, or an even split of a plane
-            if (!(SEG == HW || SEG % W == 0 || HW % SEG == 0)) continue;
-            int TT = BM / SEG;
-            if (TT > NP) TT = NP;
-            if (TT < 1) continue;
-            const int HR = SEG + 2 * W + 2;
-            const int rows = (TT + 2) * HR;
-            const int npieces = (rows + 7) / 8;
-            int lds = HALO_OFF + npieces * 8 * ROWB;
-            const int epi = HALO_OFF + NW * 64 * 144 + NW * 128 * 4 + NW * 64 * 4;
-            if (lds < epi) lds = epi;
-            if (lds > 160 * 1024) continue;
-            const int wgcu = (NW == 4 && 2 * lds <= 160 * 1024) ? 2 : 1;
-            const long tiles = (long)((NP + TT - 1) / TT) * ((HW + SEG - 1) / SEG);
-            for (int splits = 1; splits <= nchunks; splits *= 2) {
-                const int cps = (nchunks + splits - 1) / splits;
-                const long wgs = tiles * (Cn / 64) * splits;
-                const long rounds = (wgs + 256L * wgcu - 1) / (256L * wgcu);
-                const double per_tap = NW == 8 ? 1550.0 : (wgcu == 2 ? 1700.0 : 2500.0);
-                const double t_wg = 2000.0 + 7000.0 + cps * (11.5 * rows + ntaps * per_tap);
-                double cost = rounds * t_wg * (wgcu == 2 ? 1.7 : 1.0);
-                if (splits > 1) cost += 15000.0 + 2.4e3 * ((double)NP * HW * Cn * 4.0 * (splits + 0.5)) / 4.0e6;  // slabs at ~4 TB/s
-                if (cost < best) {
-                    best = cost;
-                    bp.NW = NW, bp.TT = TT, bp.SEG = SEG, bp.splits = splits;
+    // the planner only proposes 64-channel chunks: the 32-channel two-workgroup form measured no faster
+    // (its doubled weight traffic stalls the LDS-DMA issue) and stays reachable through VC_HALO_FORCE
+    const int CK = 64;
+    const int nchunks = Cs / CK;
+    for (int pad = 0; pad <= (no_pad ? 0 : 1); ++pad) {
+        for (int NW = 4; NW <= 8; NW += 4) {
+            const int BM = NW * 64;
+            for (int SEG = 1; SEG <= (HW < BM ? HW : BM); ++SEG) {
+                // segments that are whole (h) rows, whole planes, or an even split of a plane
+                if (!(SEG == HW || SEG % W == 0 || HW % SEG == 0)) continue;
+                if (pad && (SEG % W != 0 || HW % SEG != 0)) continue;  // padded form: whole h-rows, no ragged last segment
+                int TT = BM / SEG;
+                if (TT > NP) TT = NP;
+                if (pad) {
+                    if (TT > T) TT = T;
+                    while (TT > 1 && T % TT != 0) --TT;  // a tile must not straddle two samples
+                }
+                if (TT < 1) continue;
+                const int HR = pad ? (SEG / W + 2) * (W + 2) : SEG + 2 * W + 2;
+                const int rows = (TT + 2) * HR;
+                const int PR = 8;
+                const int npieces = (rows + PR - 1) / PR;
+                const int lds = halo_lds(NW, CK, npieces);
+                if (lds > 160 * 1024) continue;
+                const int wgcu = (NW == 4 && 2 * lds <= 160 * 1024) ? 2 : 1;
+                const long tiles = (long)((NP + TT - 1) / TT) * ((HW + SEG - 1) / SEG);
+                for (int splits = 1; splits <= nchunks; splits *= 2) {
+                    const int cps = (nchunks + splits - 1) / splits;
+                    const long wgs = tiles * (Cn / 64) * splits;
+                    const long rounds = (wgs + 256L * wgcu - 1) / (256L * wgcu);
+                    double per_tap = NW == 8 ? 1550.0 : (wgcu == 2 ? 1700.0 : 2500.0);
+                    if (pad) per_tap *= vc_halo_kpad / 1550.0;
+                    const double fill = 11.5 * rows;
+                    const double t_wg = 2000.0 + 7000.0 + cps * (fill + ntaps * per_tap);
+                    double cost = rounds * t_wg;
+                    if (splits > 1) cost += 15000.0 + 2.4e3 * ((double)NP * HW * Cn * 4.0 * (splits + 0.5)) / 4.0e6;
+                    if (cost < best) {
+                        best = cost;
+                        bp.NW = NW, bp.TT = TT, bp.SEG = SEG, bp.splits = splits, bp.CK = CK, bp.pad = pad;
+                    }
                 }
             }
         }
     }
     if (env) {
-        int a, b, c, d;
-        if (sscanf(env, "%d,%d,%d,%d", &a, &b, &c, &d) == 4 && (a == 4 || a == 8) && b >= 1 && c >= 1 && d >= 1 &&
-            b * c <= a * 64 && d <= nchunks)
-            bp.NW = a, bp.TT = b, bp.SEG = c, bp.splits = d;
+        int a, b, c, d, e = 64, f = 0;
+        const int nf = sscanf(env, "%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e, &f);
+        if (nf >= 4 && (a == 4 || a == 8) && b >= 1 && c >= 1 && d >= 1 && b * c <= a * 64 && (e == 64 || e == 32) &&
+            d <= Cs / e && (f == 0 || (e == 64 && c % W == 0 && HW % c == 0 && T % b == 0)))
+            bp.NW = a, bp.TT = b, bp.SEG = c, bp.splits = d, bp.CK = e, bp.pad = f;
     }
     if (bp.NW == 0) return -1;
+    static const bool verbose = getenv("VC_HALO_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "halo plan NP=%d T=%d H=%d W=%d Cs=%d Cn=%d taps=%d -> NW=%d TT=%d SEG=%d splits=%d CK=%d pad=%d\n", NP, T, H,
+                W, Cs, Cn, ntaps, bp.NW, bp.TT, bp.SEG, bp.splits, bp.CK, bp.pad);
     *plan = bp;
     return 0;
 }
@@ -461,9 +596,17 @@ int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream) 
     }
     const int HW = p.H * p.W;
     p.TT = plan.TT, p.SEG = plan.SEG;
-    p.HR = p.SEG + 2 * p.W + 2;
+    p.pad = plan.pad;
+    p.R = p.SEG / p.W, p.Wp = p.W + 2;
+    if (p.pad && (plan.CK != 64 || p.SEG % p.W != 0 || HW % p.SEG != 0 || p.T % p.TT != 0)) {
+        vc_set_error("halo conv: padded form needs whole-row segments and TT | T (TT=%d SEG=%d)", p.TT, p.SEG);
+        return -2;
+    }
+    p.HR = p.pad ? (p.R + 2) * p.Wp : p.SEG + 2 * p.W + 2;
+    p.dHR = vc_make_fastdiv(p.HR), p.dWp = vc_make_fastdiv(p.Wp);
     p.halo_rows = (p.TT + 2) * p.HR;
-    p.npieces = (p.halo_rows + 7) / 8;
+    const int PR = plan.CK == 32 ? 16 : 8;
+    p.npieces = (p.halo_rows + PR - 1) / PR;
     p.dSEG = vc_make_fastdiv(p.SEG), p.dT = vc_make_fastdiv(p.T), p.dW = vc_make_fastdiv(p.W);
     p.canon = 0;
     if (p.ntaps == 27) {
@@ -477,7 +620,8 @@ int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream) 
     }
     p.ntg = (p.NP + p.TT - 1) / p.TT;
     p.nseg = (HW + p.SEG - 1) / p.SEG;
-    if (p.TT * p.SEG > plan.NW * 64 || HALO_OFF + p.npieces * 8 * ROWB > 160 * 1024) {
+    if (p.TT * p.SEG > plan.NW * 64 || halo_lds(plan.NW, plan.CK, p.npieces) > 160 * 1024 || (plan.CK != 32 && plan.CK != 64) ||
+        (plan.CK == 32 && plan.NW != 4)) {
         vc_set_error("halo conv: plan does not fit (TT=%d SEG=%d NW=%d)", p.TT, p.SEG, plan.NW);
         return -2;
     }
@@ -487,7 +631,9 @@ int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream) 
             vc_set_error("halo conv: tap offset outside the 1-deep halo");
             return -2;
         }
-        p.taps[i].src_off = t.ot * p.HR + t.oh * p.W + t.ow;
+        p.taps[i].src_off = t.ot * p.HR + t.oh * (p.pad ? p.Wp : p.W) + t.ow;
     }
-    return plan.NW == 8 ? launch_halo<8>(p, stream) : launch_halo<4>(p, stream);
+    if (plan.CK == 32) return launch_halo<4, 32, false>(p, stream);
+    if (p.pad) return plan.NW == 8 ? launch_halo<8, 64, true>(p, stream) : launch_halo<4, 64, true>(p, stream);
+    return plan.NW == 8 ? launch_halo<8, 64, false>(p, stream) : launch_halo<4, 64, false>(p, stream);
 }

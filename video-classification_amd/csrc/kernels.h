@@ -49,6 +49,8 @@ struct VcHaloParams {
     int TT, SEG, HR, halo_rows, npieces, ntg, nseg;  // filled by vc_launch_halo from the plan
     int canon;        // +1 / -1: canonical 3x3x3 tap order (forward / mirrored), 0: generic table
     VcFastDiv dSEG, dT, dW;
+    int pad, R, Wp;   // zero-padded image form: R h-rows per segment, Wp = W + 2, HR = (R + 2) * Wp
+    VcFastDiv dHR, dWp;
     int accumulate;
     int splits, cps;
     float* partial;
@@ -57,9 +59,10 @@ struct VcHaloParams {
     VcTap taps[32];   // ot/oh/ow in [-1,1]; src_off is rewritten to the row shift inside the LDS image
 };
 struct VcHaloPlan {
-    int NW, TT, SEG, splits;
+    int NW, TT, SEG, splits, CK;  // CK: channels per K chunk (64, or 32 for two workgroups per CU)
+    int pad;                      // zero-padded LDS image (no per-tap validity selects)
 };
-int vc_halo_plan(int NP, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* plan);
+int vc_halo_plan(int NP, int T, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* plan);
 int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream);
 
 // wgrad9_conv.hip: 3x3x3 stride-1 weight gradient, nine (dh,dw) taps per LDS image

@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvc3d.so")
+LIB_PATH = os.environ.get("VC3D_LIB") or os.path.join(_HERE, "libvc3d.so")  # VC3D_LIB: experiment builds
 
 VC_STAT_REPLICAS = 32
 STEM_K = 1344
