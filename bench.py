@@ -93,7 +93,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # VC_DDP_FORCE_COMM=1 under a one-rank torchrun: keep the RCCL bucket path in the step (a rehearsal of N > 1)
+    ddp = world > 1 or (os.environ.get("VC_DDP_FORCE_COMM") == "1" and "MASTER_PORT" in os.environ)
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world and rank == 0:
@@ -117,7 +119,7 @@ def main():
     model = create_model(cfg, is_train=True).to(dev)
     criterion = Loss(cfg).to(dev)
     optimizer = create_optimizer(cfg, model)
-    net = DataParallel3D(model) if world > 1 else model
+    net = DataParallel3D(model) if ddp else model
 
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, args.clip_len, args.crop, args.crop, generator=g).to(torch.bfloat16).to(dev)
@@ -157,17 +159,17 @@ def main():
 
     # ---- timed region
     ops.TIMER = ops.KernelTimer(select=(lambda k: k == dominant)) if dominant is not None else None
-    if world > 1:
+    if ddp:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -205,7 +207,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.eval:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
 
 

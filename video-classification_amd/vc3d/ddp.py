@@ -12,8 +12,14 @@ has been issued on the compute stream, an event is recorded and the bucket's all
 enqueued on a side stream behind that event; the compute stream joins the side stream only
 at the end of backward.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# VC_DDP_FORCE_COMM=1: issue the bucket all-reduces even in a one-rank group, so that the RCCL path (side
+# stream, events, AVG reduction, join) can be exercised and timed on a single GPU (tests/test_ddp_gpu.py)
+FORCE_COMM = os.environ.get("VC_DDP_FORCE_COMM", "0") == "1"
 
 
 class GradBucketReducer:
@@ -58,7 +64,7 @@ class GradBucketReducer:
         if self.launched[b]:
             return
         self.launched[b] = True
-        if self.world == 1:
+        if self.world == 1 and not (FORCE_COMM and dist.is_initialized()):
             return
         start, end, _ = self.buckets[b]
         seg = self.flat[start:end]
@@ -81,7 +87,7 @@ class GradBucketReducer:
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)
-        if self.flat.is_cuda and self.world > 1:
+        if self.flat.is_cuda and self.works:
             for w, seg in self.works:
                 with torch.cuda.stream(self.comm_stream):
                     w.wait()
