@@ -88,15 +88,19 @@ int vc_pack_dgrad_batched(const void* shadow_bf16, void* w_dgrad_flat, const int
 /* ---- Stem: 7x7x7, 3 -> Co (multiple of 64), stride (1,2,2), pad 3.  Replaces
  * reference lib/models/backbone.py:112-113,145.  The clip [N][3][T][H][W] (fp32 or bf16,
  * H and W even) is packed once into a zero-padded space-to-depth bf16 source
- * [N][T+6][H/2+3][W/2+3][12]; the weight into [Co][1344]. The stem has no dgrad. */
+ * [N][T+6][H/2+3][Wp][12], Wp = W/2+3 rounded up to even; the weight into [Co][1344]. The stem has no dgrad. */
 size_t vc_stem_packed_input_elems(int32_t N, int32_t T, int32_t H, int32_t W);
 int vc_stem_pack_input(const void* x, int32_t x_is_bf16, void* xs, int32_t N, int32_t T, int32_t H,
                        int32_t W, void* stream);
 int vc_stem_pack_weight(const float* w_master /* [Co][7][7][7][3] */, void* ws, int32_t Co, void* stream);
 int vc_stem_fwd(const void* xs, const void* ws, void* y /* [N][T][H/2][W/2][Co] */, float* bn_stats,
                 int32_t N, int32_t T, int32_t H, int32_t W, int32_t Co, void* stream);
+/* `workspace` (device, caller-owned, nullable): per-workgroup fp32 partials of the image-resident stem weight
+ * gradient; vc_stem_wgrad_workspace_bytes reports the need (0: the generic kernel runs, as it does when the
+ * workspace is absent or too small). */
+size_t vc_stem_wgrad_workspace_bytes(int32_t N, int32_t T, int32_t H, int32_t W, int32_t Co);
 int vc_stem_wgrad(const void* xs, const void* dy, float* dws /* fp32 [Co][1344], += */, int32_t N,
-                  int32_t T, int32_t H, int32_t W, int32_t Co, void* stream);
+                  int32_t T, int32_t H, int32_t W, int32_t Co, void* workspace, size_t ws_bytes, void* stream);
 int vc_stem_unpack_wgrad(const float* dws, float* dw_master /* [Co][7][7][7][3], += */, int32_t Co,
                          void* stream);
 

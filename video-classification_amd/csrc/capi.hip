@@ -454,14 +454,14 @@ static int stem_check(int N, int T, int H, int W, int Co) {
     VC_REQUIRE(N > 0 && T > 0 && H > 0 && W > 0, "stem: bad dims");
     VC_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H=%d and W=%d must be even", H, W);
     VC_REQUIRE(Co % 64 == 0 && Co > 0, "stem: Co=%d must be a multiple of 64", Co);
-    const long long in_e = (long long)N * (T + 6) * (H / 2 + 3) * (W / 2 + 3) * 12;
+    const long long in_e = (long long)N * (T + 6) * (H / 2 + 3) * ((W / 2 + 4) & ~1) * 12;
     const long long out_e = (long long)N * T * (H / 2) * (W / 2) * Co;
     VC_REQUIRE(in_e < (1ll << 31) && out_e < (1ll << 31), "stem: tensor exceeds 2^31 elements; split the batch");
     return 0;
 }
 
 size_t vc_stem_packed_input_elems(int32_t N, int32_t T, int32_t H, int32_t W) {
-    return (size_t)N * (T + 6) * (H / 2 + 3) * (W / 2 + 3) * 12;
+    return (size_t)N * (T + 6) * (H / 2 + 3) * ((W / 2 + 4) & ~1) * 12;
 }
 
 int vc_stem_pack_input(const void* x, int32_t x_is_bf16, void* xs, int32_t N, int32_t T, int32_t H, int32_t W,
@@ -479,7 +479,7 @@ int vc_stem_pack_weight(const float* w_master, void* ws, int32_t Co, void* strea
 
 static void stem_geometry(int N, int T, int H, int W, int& M, int& Ho, int& Wo, int& Tp, int& Hp, int& Wp) {
     Ho = H / 2, Wo = W / 2;
-    Tp = T + 6, Hp = Ho + 3, Wp = Wo + 3;
+    Tp = T + 6, Hp = Ho + 3, Wp = (Wo + 4) & ~1;  // row pitch rounded to an even count: 16-byte rows
     M = N * T * Ho * Wo;
 }
 
@@ -508,13 +508,31 @@ int vc_stem_fwd(const void* xs, const void* ws, void* y, float* bn_stats, int32_
     return vc_launch_igemm(p, 1, S(stream));
 }
 
+size_t vc_stem_wgrad_workspace_bytes(int32_t N, int32_t T, int32_t H, int32_t W, int32_t Co) {
+    if (stem_check(N, T, H, W, Co)) return 0;
+    int M, Ho, Wo, Tp, Hp, Wp;
+    stem_geometry(N, T, H, W, M, Ho, Wo, Tp, Hp, Wp);
+    VcStemWgradParams sp;
+    if (!vc_stem_wgrad_plan(N, T, Ho, Wo, Hp, Wp, Co, &sp)) return 0;
+    return vc_stem_wgrad_slab_bytes(sp);
+}
+
 int vc_stem_wgrad(const void* xs, const void* dy, float* dws, int32_t N, int32_t T, int32_t H, int32_t W, int32_t Co,
-                  void* stream) {
+                  void* workspace, size_t ws_bytes, void* stream) {
     int rc = stem_check(N, T, H, W, Co);
     if (rc) return rc;
     VC_REQUIRE(xs && dy && dws, "stem_wgrad: null pointer");
     int M, Ho, Wo, Tp, Hp, Wp;
     stem_geometry(N, T, H, W, M, Ho, Wo, Tp, Hp, Wp);
+    // image-resident form (persistent workgroups, per-workgroup fp32 slabs in the workspace)
+    VcStemWgradParams sp;
+    if (workspace != nullptr && vc_stem_wgrad_plan(N, T, Ho, Wo, Hp, Wp, Co, &sp) &&
+        ws_bytes >= vc_stem_wgrad_slab_bytes(sp)) {
+        sp.xs = (const bf16*)xs;
+        sp.dy = (const bf16*)dy;
+        sp.slabs = (float*)workspace;
+        return vc_launch_stem_wgrad(sp, dws, S(stream));
+    }
     VcWgradParams p;
     memset(&p, 0, sizeof(p));
     p.x = (const bf16*)xs;

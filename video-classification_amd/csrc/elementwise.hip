@@ -661,11 +661,12 @@ __global__ void linear_bwd_weight_kernel(const float* __restrict__ dlog, const f
 
 // ------------------------------------------------------------------ layout
 // clip batch x [N][3][T][H][W] (fp32 or bf16) -> zero-padded space-to-depth stem source
-// xs [N][T+6][H/2+3][W/2+3][12], channel = (bh*2 + bw)*3 + c, pads: T 3/3, H' 2/1, W' 2/1
+// xs [N][T+6][H/2+3][Wp][12], Wp = W/2+3 rounded up to even (rows are then whole 16-byte units: LDS-DMA),
+// channel = (bh*2 + bw)*3 + c, pads: T 3/3, H' 2/1, W' 2/1(+1)
 template <typename TIN>
 __global__ __launch_bounds__(256) void stem_pack_input_kernel(const TIN* __restrict__ x, bf16* __restrict__ xs, int N, int T,
                                                               int H, int W) {
-    const int Tp = T + 6, Hp = H / 2 + 3, Wp = W / 2 + 3;
+    const int Tp = T + 6, Hp = H / 2 + 3, Wp = (W / 2 + 4) & ~1;
     const long total = (long)N * Tp * Hp * Wp;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -1021,7 +1022,7 @@ int vc_ew_linear_bwd(const float* dlog, const float* feat, const float* W, float
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_stem_pack_input(const void* x, int x_is_bf16, void* xs, int N, int T, int H, int W, hipStream_t s) {
-    const long total = (long)N * (T + 6) * (H / 2 + 3) * (W / 2 + 3);
+    const long total = (long)N * (T + 6) * (H / 2 + 3) * ((W / 2 + 4) & ~1);
     if (x_is_bf16)
         VC_LAUNCH((stem_pack_input_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)x,
                            (bf16*)xs, N, T, H, W);

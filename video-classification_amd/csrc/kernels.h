@@ -80,6 +80,20 @@ struct VcWgrad9Params {
 int vc_wgrad9_plan(long M, int W, int Cs, int Co, int* rows_per_split);  // splits; 0 = geometry not supported
 int vc_launch_wgrad9(VcWgrad9Params& p, hipStream_t stream);
 
+// stem_wgrad.hip: stem weight gradient with the raw space-to-depth rows resident in LDS (persistent workgroups)
+struct VcStemWgradParams {
+    const bf16* xs;  // [N][Tp][Hp][Wp][12], Wp even
+    const bf16* dy;  // [N*T*Ho*Wo][64]
+    float* slabs;    // [grid][64][1344] fp32 partials
+    int N, T, Ho, Wo, Tp, Hp, Wp;
+    int RH, KS;      // output rows per chunk, 32-row k-steps per chunk
+    int TR, nhg, ntr, units;  // frames per unit, row groups, frame ranges, units = N * nhg * ntr
+    int plane_pieces, grid, lds_bytes;
+};
+int vc_stem_wgrad_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcStemWgradParams* out);  // 0 = not applicable
+size_t vc_stem_wgrad_slab_bytes(const VcStemWgradParams& p);
+int vc_launch_stem_wgrad(VcStemWgradParams& p, float* dws, hipStream_t stream);
+
 int vc_launch_igemm(const VcIgemmParams& p, int mode, hipStream_t stream);
 int vc_launch_wgrad(const VcWgradParams& p, int mode, hipStream_t stream);
 // split-K planning (shared by the workspace query and the launch)

@@ -68,7 +68,8 @@ PROTOTYPES = {
     "vc_stem_pack_input": [_P, _I, _P, _I, _I, _I, _I, _P],
     "vc_stem_pack_weight": [_P, _P, _I, _P],
     "vc_stem_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "vc_stem_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vc_stem_wgrad_workspace_bytes": [_I, _I, _I, _I, _I],
+    "vc_stem_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P, C.c_size_t, _P],
     "vc_stem_unpack_wgrad": [_P, _P, _I, _P],
     "vc_bn_stats": [_P, _P, _L, _I, _P],
     "vc_bn_finalize": [_P, _I, _F, _P, _P, _P, _P, _F, _F, _P, _P],
@@ -91,7 +92,7 @@ PROTOTYPES = {
     "vc_nthwc_to_ncthw": [_P, _P, _I, _I, _I, _L, _P],
 }
 _RESTYPE = {"vc_last_error": C.c_char_p, "vc_stem_packed_input_elems": C.c_size_t,
-            "vc_conv3d_workspace_bytes": C.c_size_t}
+            "vc_conv3d_workspace_bytes": C.c_size_t, "vc_stem_wgrad_workspace_bytes": C.c_size_t}
 
 
 def _load():

@@ -68,11 +68,12 @@ _WS = {}  # device -> split-K workspace (grown on demand; reuse is safe: launche
 USE_WORKSPACE = True
 
 
-def _workspace(d, op, device):
+def _workspace(d, op, device, need=None):
     """(ptr, bytes) of a workspace large enough for conv `d`, op 0/1/2; (None, 0) if none is needed."""
     if not USE_WORKSPACE:
         return None, 0
-    need = int(lib.vc_conv3d_workspace_bytes(d, op))
+    if need is None:
+        need = int(lib.vc_conv3d_workspace_bytes(d, op))
     if need == 0:
         return None, 0
     key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
@@ -190,6 +191,11 @@ def pack_dgrad_batched(shadow, wd_flat, table_dev, table_host):
 
 
 # ------------------------------------------------------------------ stem
+def stem_wp(W):
+    """row pitch (positions) of the packed stem source: W/2 + 3 rounded up to even."""
+    return (W // 2 + 4) & ~1
+
+
 def stem_pack_input(x):
     """x: [N][3][T][H][W] fp32 or bf16 (contiguous) -> padded space-to-depth bf16 source."""
     N, Cc, T, H, W = x.shape
@@ -198,7 +204,7 @@ def stem_pack_input(x):
     if x.dtype not in (F32, BF16):
         raise capi.Vc3dError("stem input must be fp32 or bf16")
     _chk(x, x.dtype, name="clip")
-    xs = torch.empty(N, T + 6, H // 2 + 3, W // 2 + 3, 12, dtype=BF16, device=x.device)
+    xs = torch.empty(N, T + 6, H // 2 + 3, stem_wp(W), 12, dtype=BF16, device=x.device)
     check(lib.vc_stem_pack_input(ptr(x), 1 if x.dtype == BF16 else 0, ptr(xs), N, T, H, W, cur_stream()),
           "vc_stem_pack_input")
     return xs
@@ -216,7 +222,7 @@ def stem_pack_weight(w_master):
 
 
 def stem_fwd(xs, ws, N, T, H, W, Co, stats=None, out=None):
-    _chk(xs, BF16, N * (T + 6) * (H // 2 + 3) * (W // 2 + 3) * 12, "xs")
+    _chk(xs, BF16, N * (T + 6) * (H // 2 + 3) * stem_wp(W) * 12, "xs")
     _chk(ws, BF16, Co * STEM_K, "ws")
     if out is None:
         out = torch.empty(N, T, H // 2, W // 2, Co, dtype=BF16, device=xs.device)
@@ -232,7 +238,7 @@ def stem_fwd(xs, ws, N, T, H, W, Co, stats=None, out=None):
 
 def stem_wgrad(xs, dy, N, T, H, W, Co, dw_master_phys, scratch=None):
     """dw_master_phys: fp32 [Co][7][7][7][3] physical view of the stem gradient, accumulated into."""
-    _chk(xs, BF16, N * (T + 6) * (H // 2 + 3) * (W // 2 + 3) * 12, "xs")
+    _chk(xs, BF16, N * (T + 6) * (H // 2 + 3) * stem_wp(W) * 12, "xs")
     _chk(dy, BF16, N * T * (H // 2) * (W // 2) * Co, "dy")
     _chk(dw_master_phys, F32, Co * 1029, "dw")
     if scratch is None:
@@ -242,7 +248,8 @@ def stem_wgrad(xs, dy, N, T, H, W, Co, dw_master_phys, scratch=None):
         scratch.zero_()
     flops = 2.0 * N * T * (H // 2) * (W // 2) * Co * 1029
     ev = TIMER.begin(("stem_wgrad", N, T, H, W, Co), flops) if TIMER is not None else None
-    check(lib.vc_stem_wgrad(ptr(xs), ptr(dy), ptr(scratch), N, T, H, W, Co, cur_stream()), "vc_stem_wgrad")
+    ws, wsb = _workspace(None, 2, xs.device, need=int(lib.vc_stem_wgrad_workspace_bytes(N, T, H, W, Co)))
+    check(lib.vc_stem_wgrad(ptr(xs), ptr(dy), ptr(scratch), N, T, H, W, Co, ws, wsb, cur_stream()), "vc_stem_wgrad")
     if ev is not None:
         ev.record()
     check(lib.vc_stem_unpack_wgrad(ptr(scratch), ptr(dw_master_phys), Co, cur_stream()), "vc_stem_unpack_wgrad")
