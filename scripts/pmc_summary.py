@@ -49,13 +49,14 @@ def main():
                          active_inst=m.get("SQ_ACTIVE_INST_ANY", 0.0) * 4, lds_conf=m.get("SQ_LDS_BANK_CONFLICT", 0.0),
                          lds_active=m.get("SQ_LDS_IDX_ACTIVE", 0.0)))
     rows.sort(key=lambda r: -(r["gui"] * r["launches"]))
-    print("%-90s %5s %10s %10s %9s %9s %8s %8s" % ("kernel (per-launch means)", "n", "HBM rd MB", "HBM wr MB", "GUI kclk", "mfma/SIMD",
+    print("%-90s %5s %10s %10s %9s %9s %8s %8s" % ("kernel (per-launch means)", "n", "HBM rd MB", "HBM wr MB", "kclk", "mfma busy",
                                                      "wait%", "ldsconf%"))
     for r in rows[:args.top]:
-        # SQ_VALU_MFMA_BUSY_CYCLES sums over the chip's 1024 SIMDs: share of (GRBM_GUI_ACTIVE x 1024)
-        util = r["mfma_busy"] / (r["gui"] * 1024) if r["gui"] else 0.0
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs (checked against the kernel-trace durations);
+        # SQ_VALU_MFMA_BUSY_CYCLES over the chip's 1024 SIMDs: MFMA-pipe busy share = busy / (gui / 8 * 1024)
+        util = r["mfma_busy"] / (r["gui"] / 8.0 * 1024) if r["gui"] else 0.0
         print("%-90s %5d %10.2f %10.2f %9.1f %9.3f %8.1f %8.1f" % (
-            short(r["kernel"]), r["launches"], r["hbm_read_B"] / 1e6, r["hbm_write_B"] / 1e6, r["gui"] / 1e3, util,
+            short(r["kernel"]), r["launches"], r["hbm_read_B"] / 1e6, r["hbm_write_B"] / 1e6, r["gui"] / 8e3, util,
             100.0 * r["wait_any"] / r["wave_cycles"] if r["wave_cycles"] else 0.0,
             100.0 * r["lds_conf"] / r["lds_active"] if r["lds_active"] else 0.0))
     if args.csv:
