@@ -490,6 +490,14 @@ int vc_stem_fwd(const void* xs, const void* ws, void* y, float* bn_stats, int32_
     VC_REQUIRE(xs && ws && y, "stem_fwd: null pointer");
     int M, Ho, Wo, Tp, Hp, Wp;
     stem_geometry(N, T, H, W, M, Ho, Wo, Tp, Hp, Wp);
+    VcStemFwdParams sp;
+    if (vc_stem_fwd_plan(N, T, Ho, Wo, Hp, Wp, Co, &sp)) {  // image-resident form
+        sp.xs = (const bf16*)xs;
+        sp.ws = (const bf16*)ws;
+        sp.y = (bf16*)y;
+        sp.stats = bn_stats;
+        return vc_launch_stem_fwd(sp, S(stream));
+    }
     VcIgemmParams p;
     memset(&p, 0, sizeof(p));
     p.src = (const bf16*)xs;

@@ -94,6 +94,20 @@ int vc_stem_wgrad_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcS
 size_t vc_stem_wgrad_slab_bytes(const VcStemWgradParams& p);
 int vc_launch_stem_wgrad(VcStemWgradParams& p, float* dws, hipStream_t stream);
 
+// stem_fwd.hip: stem forward with the raw space-to-depth rows resident in LDS (persistent workgroups)
+struct VcStemFwdParams {
+    const bf16* xs;  // [N][Tp][Hp][Wp][12], Wp even
+    const bf16* ws;  // [64][1344]
+    bf16* y;         // [N*T*Ho*Wo][64]
+    float* stats;    // nullable: [VC_STAT_REPLICAS][2][64]
+    int N, T, Ho, Wo, Tp, Hp, Wp;
+    int RH;          // output rows per chunk (RH * Wo <= 224)
+    int TR, nhg, ntr, units;
+    int plane_pieces, grid, lds_bytes;
+};
+int vc_stem_fwd_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcStemFwdParams* out);  // 0 = not applicable
+int vc_launch_stem_fwd(VcStemFwdParams& p, hipStream_t stream);
+
 int vc_launch_igemm(const VcIgemmParams& p, int mode, hipStream_t stream);
 int vc_launch_wgrad(const VcWgradParams& p, int mode, hipStream_t stream);
 // split-K planning (shared by the workspace query and the launch)

@@ -1,0 +1,268 @@
+// Stem (7x7x7, 3 -> 64, stride (1,2,2)) forward on bf16 MFMA (gfx950), image-resident form.
+//
+// Y[m][co] = sum_k Xs[pos(m) + off(k)] * Ws[co][k],  k = kt*192 + ah*48 + j,  j = aw*12 + c12, over the
+// space-to-depth source xs [N][T+6][Hp][Wp][12] (24 bytes per position).  For a fixed (kt, ah) the 48 values of
+// j are contiguous in xs, so the 8 consecutive k of an MFMA B-fragment lane are 16 contiguous bytes of the raw
+// image row (8-byte aligned: two ds_read_b64).  The implicit-GEMM kernel this replaces gathered an im2col tile
+// through the vector-memory pipe in 8-byte pieces and was bound by that pipe; here the raw rows of the 7
+// source frames sit in LDS (a ring of 10 plane slots filled by LDS-DMA, each plane = RH+3 padded rows = one
+// contiguous global range) and no im2col tile exists.
+//
+// Persistent workgroups of 7 waves.  Work unit = (sample, group of RH output rows, range of TR frames); frames
+// are processed in pairs: a chunk of RH x Wo <= 224 positions per frame, wave w owns positions [32w, 32w+32)
+// of both frames x all 64 co = 16 accumulator tiles.  The weights stream through LDS one temporal tap at a
+// time (64 x 192 bf16, 416-byte row pitch produced on the DMA's source side, double-buffered, one barrier per
+// tap); A = weights (so a lane ends with 4 consecutive channels of one position), B = image.
+// Epilogue per frame pair: bf16 channels-last stores straight from the accumulators; BatchNorm sum / sum of
+// squares are kept in registers over the workgroup's whole share and leave as 128 atomics per workgroup.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __attribute__((aligned(128))) unsigned int vc_stemf_zero_page[32];  // zero source of out-of-range DMA lanes
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#ifndef VC_STEMF_ABLATE
+#define VC_STEMF_ABLATE 0  // timing experiments only: 1 = weight tiles not refilled, 2 = image planes not refilled
+#endif
+constexpr int NWAVE = 7;
+constexpr int WPITCH = 416;          // bytes per weight row in LDS: 384 data + 32 pad (conflict-free ds_read_b128)
+constexpr int WPIECES = 26;          // 64 rows x 26 slots of 16 bytes = 26 pieces of 1 KiB
+constexpr int WBUF = WPIECES * 1024;
+constexpr int NSLOT = 10;            // plane ring: 8 planes of the current frame pair + 2 of the next
+constexpr int W_OFF = 0;
+constexpr int PL_OFF = 2 * WBUF;
+
+__global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem_fwd_kernel(
+    const VcStemFwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int RP = p.Wp * 24;
+    const int PLB = p.plane_pieces * 1024;
+    const int CP = p.RH * p.Wo;
+    const gptr_t zero = (gptr_t)vc_stemf_zero_page;
+
+    // this lane's two positions (B columns) of the chunk, and the k offsets of its 8-element group per k-step
+    int mloc[2], posoff[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        mloc[nt] = wave * 32 + nt * 16 + l15;
+        const int hl = mloc[nt] / p.Wo;
+        const int w = mloc[nt] - hl * p.Wo;
+        posoff[nt] = mloc[nt] < CP ? hl * RP + w * 24 : 0;
+    }
+    int koff[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const int k = ks * 32 + lg * 8;
+        const int ah = k / 48;
+        koff[ks] = ah * RP + (k - ah * 48) * 2;
+    }
+    const int aoff = l15 * WPITCH + lg * 16;
+
+    float ssum[4][4], ssq[4][4];  // BatchNorm partial sums of this lane's channels co = a*16 + lg*4 + j
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ssum[a][j] = 0.f, ssq[a][j] = 0.f;
+
+    auto issue_plane = [&](int n, int tp, int h0) {
+        char* dst = smem + PL_OFF + (tp % NSLOT) * PLB;
+        const int rows_valid = min(p.RH + 3, p.Hp - h0);
+        const int valid_bytes = tp < p.Tp ? rows_valid * RP : 0;
+        const char* src0 = (const char*)(p.xs + ((size_t)((n * p.Tp + min(tp, p.Tp - 1)) * p.Hp + h0) * p.Wp) * 12);
+        for (int pc = wave; pc < p.plane_pieces; pc += NWAVE) {
+            const int o = pc * 1024 + lane * 16;
+            const gptr_t src = o < valid_bytes ? (gptr_t)(src0 + o) : zero;
+            __builtin_amdgcn_global_load_lds(src, (lptr_t)(dst + pc * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_w = [&](int kt, int buf) {
+        char* dst = smem + W_OFF + buf * WBUF;
+        for (int pc = wave; pc < WPIECES; pc += NWAVE) {
+            const unsigned S = (unsigned)(pc * 64 + lane);
+            const unsigned row = (S * 2521u) >> 16;  // S / 26 for S < 1664
+            const unsigned part = S - row * 26u;
+            const gptr_t src = part < 24u ? (gptr_t)(p.ws + ((size_t)row * 1344 + kt * 192 + part * 8)) : zero;
+            __builtin_amdgcn_global_load_lds(src, (lptr_t)(dst + pc * 1024), 16, 0, 0);
+        }
+    };
+
+    for (int u = blockIdx.x; u < p.units; u += gridDim.x) {
+        const int tr = u % p.ntr;
+        const int hg = (u / p.ntr) % p.nhg;
+        const int n = u / (p.ntr * p.nhg);
+        const int t0 = tr * p.TR;
+        const int t1 = min(p.T, t0 + p.TR);
+        const int h0 = hg * p.RH;
+        const int cpv = min(p.RH, p.Ho - h0) * p.Wo;  // valid positions of this row group
+        __syncthreads();  // the previous unit's last reads are done: ring and weight buffers may be refilled
+        for (int tp = t0; tp < t0 + 8; ++tp) issue_plane(n, tp, h0);
+        issue_w(0, 0);
+        int wbuf = 0;
+        for (int t = t0; t < t1; t += 2) {
+            f32x4 acc[4][2][2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[a][f][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int kt = 0; kt < 7; ++kt) {
+                __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): everything issued so far has landed
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#if !(VC_STEMF_ABLATE & 1)
+                if (kt < 6) issue_w(kt + 1, wbuf ^ 1);
+                else if (t + 2 < t1) issue_w(0, wbuf ^ 1);
+#endif
+                if (!(VC_STEMF_ABLATE & 2) && kt == 0 && t + 2 < t1) {  // the planes only the next pair needs, into the slots of planes t-2, t-1
+                    issue_plane(n, t + 8, h0);
+                    issue_plane(n, t + 9, h0);
+                }
+                const char* sW = smem + W_OFF + wbuf * WBUF + aoff;
+                const char* pl0 = smem + PL_OFF + ((t + kt) % NSLOT) * PLB;
+                const char* pl1 = smem + PL_OFF + ((t + 1 + kt) % NSLOT) * PLB;
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) {
+                    bf16x8 fa[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) fa[a] = *(const bf16x8*)(sW + a * 16 * WPITCH + ks * 64);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const char* bp = (f ? pl1 : pl0) + posoff[nt] + koff[ks];
+                            const bf16x4 lo = *(const bf16x4*)bp;
+                            const bf16x4 hi = *(const bf16x4*)(bp + 8);
+                            const bf16x8 fb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                            for (int a = 0; a < 4; ++a)
+                                acc[a][f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[a][f][nt], 0, 0, 0);
+                        }
+                }
+                wbuf ^= 1;
+            }
+            // ---- acc[a][f][nt][j] = Y[frame t+f][position mloc[nt]][co = a*16 + lg*4 + j]
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                if (t + f >= t1) continue;
+                const long mrow = ((long)(n * p.T + t + f) * p.Ho + h0) * p.Wo;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    if (mloc[nt] >= cpv) continue;
+                    bf16* dst = p.y + (mrow + mloc[nt]) * 64 + lg * 4;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const f32x4 v = acc[a][f][nt];
+                        *(bf16x4*)(dst + a * 16) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            ssum[a][j] += v[j];
+                            ssq[a][j] += v[j] * v[j];
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- BatchNorm sums: 16 positions (l15) -> wave -> workgroup -> one atomic per channel and moment
+    if (p.stats != nullptr) {
+        __syncthreads();
+        float* sred = (float*)smem;  // [NWAVE][2][64]
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = ssum[a][j], q2 = ssq[a][j];
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) {
+                    s += __shfl_xor(s, o, 16);
+                    q2 += __shfl_xor(q2, o, 16);
+                }
+                if (l15 == 0) {
+                    sred[wave * 128 + a * 16 + lg * 4 + j] = s;
+                    sred[wave * 128 + 64 + a * 16 + lg * 4 + j] = q2;
+                }
+            }
+        __syncthreads();
+        if (tid < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) s += sred[w * 128 + tid];
+            float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * 64;
+            atomicAdd(srep + (tid < 64 ? 0 : 64) + (tid & 63), s);
+        }
+    }
+}
+
+}  // namespace
+
+// Geometry / plan.  Returns 0 when the image-resident form does not apply (then the implicit GEMM runs).
+int vc_stem_fwd_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcStemFwdParams* out) {
+    static const bool off = getenv("VC_NO_STEM_FWD2") != nullptr;
+    if (off || Co != 64 || (Wp & 1)) return 0;
+    VcStemFwdParams p;
+    memset(&p, 0, sizeof(p));
+    const int RP = Wp * 24;
+    int best_rh = 0;
+    double best_eff = 0.0;
+    for (int RH = 1; RH <= Ho && RH * Wo <= NWAVE * 32; ++RH) {
+        const int pieces = ((RH + 3) * RP + 1023) / 1024;
+        const long lds = 2L * WBUF + (long)NSLOT * pieces * 1024;
+        if (lds > 160 * 1024) break;
+        const int nhg = (Ho + RH - 1) / RH;
+        const double eff = ((double)Ho * Wo / ((double)nhg * NWAVE * 32)) * ((double)RH / (RH + 1.0));
+        if (eff > best_eff) best_eff = eff, best_rh = RH;
+    }
+    if (best_rh == 0) return 0;
+    p.N = N, p.T = T, p.Ho = Ho, p.Wo = Wo, p.Tp = T + 6, p.Hp = Hp, p.Wp = Wp;
+    p.RH = best_rh;
+    p.plane_pieces = ((best_rh + 3) * RP + 1023) / 1024;
+    p.nhg = (Ho + best_rh - 1) / best_rh;
+    const int target = getenv("VC_STEM_FWD_WGS") ? atoi(getenv("VC_STEM_FWD_WGS")) : 256;
+    double best_cost = 1e30;
+    for (int cand = 1; cand <= T; ++cand) {
+        const int TR = (T + cand - 1) / cand;
+        const int nr = (T + TR - 1) / TR;
+        const long units = (long)N * p.nhg * nr;
+        const long wgs = units < target ? units : target;
+        const long per = (units + wgs - 1) / wgs;
+        const double cost = (double)per * ((TR + 1) / 2 + 0.7);  // frame pairs + ring start-up
+        if (cost < best_cost) best_cost = cost, p.ntr = nr, p.TR = TR;
+    }
+    p.units = N * p.nhg * p.ntr;
+    p.grid = p.units < target ? p.units : target;
+    p.lds_bytes = 2 * WBUF + NSLOT * p.plane_pieces * 1024;
+    *out = p;
+    return 1;
+}
+
+int vc_launch_stem_fwd(VcStemFwdParams& p, hipStream_t stream) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)stem_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[dev] = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(p.grid), dim3(NWAVE * 64), p.lds_bytes, stream, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        vc_set_error("stem fwd launch failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
+}
