@@ -120,12 +120,15 @@ def _conv_case(case):
     assert rel_l2(dw_h, w.grad) <= TOL_F32
 
 
-@pytest.mark.parametrize("shape", [(2, 4, 16, 16), (1, 1, 12, 20), (3, 5, 8, 8)])
+# the last shapes: ragged last row group + odd T (image-resident kernels: several units, frame pairs with an idle
+# second frame), a wide image (3 rows per chunk, 4 output rows), and Co = 128 (the generic kernels)
+@pytest.mark.parametrize("shape", [(2, 4, 16, 16), (1, 1, 12, 20), (3, 5, 8, 8), (1, 7, 80, 24), (2, 3, 8, 120),
+                                   (1, 2, 16, 16, 128)])
 def test_stem_fwd_wgrad(shape):
     _need_gpu()
     from vc3d import ops
-    N, T, H, W = shape
-    Co = 64
+    N, T, H, W = shape[:4]
+    Co = shape[4] if len(shape) > 4 else 64
     g = torch.Generator().manual_seed(7 + N)
     x = bf16_round(torch.randn(N, 3, T, H, W, generator=g))
     w = bf16_round(torch.randn(Co, 3, 7, 7, 7, generator=g) * (2.0 / (64 * 343)) ** 0.5 * 4)
