@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""How long the host takes to ENQUEUE one training step (no synchronisation inside the step): if this is well
+below the GPU step time the run is GPU-bound and one process per GPU scales without host contention."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "video-classification_amd"))
+import _init_paths  # noqa
+import torch
+from core.config import config
+from core.loss import Loss
+from models.model import create_model
+from utils.utils import create_optimizer
+cfg = config.clone(); cfg.MODEL.RESNET_TYPE = 18; cfg.MODEL.CLFDIM = 101; cfg.MODEL.INIT_WEIGHTS = False
+cfg.TRAIN.OPTIMIZER = "sgd"; cfg.TRAIN.LR = 0.001
+model = create_model(cfg, is_train=True).cuda(); crit = Loss(cfg).cuda(); opt = create_optimizer(cfg, model)
+x = torch.randn(64, 3, 16, 112, 112).to(torch.bfloat16).cuda(); y = torch.randint(0, 101, (64,)).cuda()
+model.train()
+def step():
+    _, s, _ = model(x); loss = crit(s, y, None, None); opt.zero_grad(); loss.backward(); opt.step()
+for _ in range(5): step()
+torch.cuda.synchronize()
+ts = []
+for _ in range(10):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    ts.append((t1 - t0, t2 - t0))
+print("host enqueue ms: median %.3f; step ms (enqueue + drain): median %.3f" % (1e3 * sorted(t[0] for t in ts)[5], 1e3 * sorted(t[1] for t in ts)[5]))

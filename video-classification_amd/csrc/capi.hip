@@ -295,55 +295,85 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
             }
         }
     }
+    // every stride-parity class of input positions is its own small GEMM (own taps, own output lattice): they go
+    // out as ONE launch (blockIdx.z = class) when their tap tables fit together, else one launch per class
+    VcIgemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.src = (const bf16*)dy;
+    p.wgt = (const bf16*)w_dgrad;
+    p.out = (bf16*)dx;
+    p.stats = nullptr;
+    p.Ts = To, p.Hs = Ho, p.Ws = Wo, p.Cs = d->Co;
+    p.st = p.sh = p.sw = 1;
+    p.Kw = ntaps_all * d->Co;
+    p.Cn = d->Ci;
+    p.out_w = d->sw * d->Ci;
+    p.out_h = d->sh * d->Wi * d->Ci;
+    p.out_t = d->st * d->Hi * d->Wi * d->Ci;
+    p.out_n = d->Ti * d->Hi * d->Wi * d->Ci;
+    p.accumulate = accumulate;
+    if (splits > 1) {
+        p.splits = splits;
+        p.partial = (float*)workspace;
+        p.partial_stride = (long long)dx_e;
+    }
+    int ncls = 0, ntap = 0, maxM = 0;
+    const bool batch = ntaps_all <= 32 && d->st * d->sh * d->sw <= 8 && getenv("VC_NO_DGRAD_BATCH") == nullptr;
     for (int rt = 0; rt < d->st; ++rt)
         for (int rh = 0; rh < d->sh; ++rh)
             for (int rw = 0; rw < d->sw; ++rw) {
-                VcIgemmParams p;
-                memset(&p, 0, sizeof(p));
-                p.src = (const bf16*)dy;
-                p.wgt = (const bf16*)w_dgrad;
-                p.out = (bf16*)dx;
-                p.stats = nullptr;
-                p.Ta = (d->Ti - rt + d->st - 1) / d->st;
-                p.Ha = (d->Hi - rh + d->sh - 1) / d->sh;
-                p.Wa = (d->Wi - rw + d->sw - 1) / d->sw;
-                if (p.Ta <= 0 || p.Ha <= 0 || p.Wa <= 0) continue;
-                p.M = d->N * p.Ta * p.Ha * p.Wa;
-                p.dWa = vc_make_fastdiv(p.Wa), p.dHa = vc_make_fastdiv(p.Ha), p.dTa = vc_make_fastdiv(p.Ta);
-                p.Ts = To, p.Hs = Ho, p.Ws = Wo, p.Cs = d->Co;
-                p.st = p.sh = p.sw = 1;
-                p.Kw = ntaps_all * d->Co;
-                p.Cn = d->Ci;
-                p.out_w = d->sw * d->Ci;
-                p.out_h = d->sh * d->Wi * d->Ci;
-                p.out_t = d->st * d->Hi * d->Wi * d->Ci;
-                p.out_n = d->Ti * d->Hi * d->Wi * d->Ci;
-                p.out_base = ((rt * d->Hi + rh) * d->Wi + rw) * d->Ci;
-                p.accumulate = accumulate;
+                VcIgemmParams::Class c;
+                memset(&c, 0, sizeof(c));
+                c.Ta = (d->Ti - rt + d->st - 1) / d->st;
+                c.Ha = (d->Hi - rh + d->sh - 1) / d->sh;
+                c.Wa = (d->Wi - rw + d->sw - 1) / d->sw;
+                if (c.Ta <= 0 || c.Ha <= 0 || c.Wa <= 0) continue;
+                c.M = d->N * c.Ta * c.Ha * c.Wa;
+                c.dWa = vc_make_fastdiv(c.Wa), c.dHa = vc_make_fastdiv(c.Ha), c.dTa = vc_make_fastdiv(c.Ta);
+                c.out_base = ((rt * d->Hi + rh) * d->Wi + rw) * d->Ci;
+                c.tap0 = batch ? ntap : 0;
                 int n = 0, i = 0;
                 for (int a = 0; a < d->kt; ++a)
                     for (int b = 0; b < d->kh; ++b)
-                        for (int c = 0; c < d->kw; ++c, ++i) {
-                            const int nt = rt + d->pt - a, nh = rh + d->ph - b, nw = rw + d->pw - c;
+                        for (int cc = 0; cc < d->kw; ++cc, ++i) {
+                            const int nt = rt + d->pt - a, nh = rh + d->ph - b, nw = rw + d->pw - cc;
                             if (posmod(nt, d->st) || posmod(nh, d->sh) || posmod(nw, d->sw)) continue;
-                            VcTap& t = p.taps[n++];
+                            VcTap& t = p.taps[c.tap0 + n++];
                             t.ot = (short)floordiv(nt, d->st), t.oh = (short)floordiv(nh, d->sh),
                             t.ow = (short)floordiv(nw, d->sw);
                             t.src_off = ((t.ot * Ho + t.oh) * Wo + t.ow) * d->Co;
                             t.wk_off = i * d->Co;
                         }
-                p.ntaps = n;
+                c.ntaps = n;
                 if (n == 0) continue;
-                if (splits > 1) {
-                    const int nchunks = n * (d->Co / 64);
-                    p.splits = splits;
-                    p.cps = (nchunks + splits - 1) / splits;
-                    p.partial = (float*)workspace;
-                    p.partial_stride = (long long)dx_e;
+                if (batch) {
+                    p.cls[ncls++] = c;
+                    ntap += n;
+                    if (c.M > maxM) maxM = c.M;
+                    continue;
                 }
+                p.ncls = 0;
+                p.M = c.M, p.Ta = c.Ta, p.Ha = c.Ha, p.Wa = c.Wa, p.dWa = c.dWa, p.dHa = c.dHa, p.dTa = c.dTa;
+                p.out_base = c.out_base, p.ntaps = n;
+                if (splits > 1) p.cps = (n * (d->Co / 64) + splits - 1) / splits;
                 rc = vc_launch_igemm(p, 0, S(stream));
                 if (rc) return rc;
             }
+    if (batch && ncls > 0) {
+        if (ncls == 1) {  // a single class: the plain form
+            const VcIgemmParams::Class& c = p.cls[0];
+            p.ncls = 0;
+            p.M = c.M, p.Ta = c.Ta, p.Ha = c.Ha, p.Wa = c.Wa, p.dWa = c.dWa, p.dHa = c.dHa, p.dTa = c.dTa;
+            p.out_base = c.out_base, p.ntaps = c.ntaps;
+            if (splits > 1) p.cps = (c.ntaps * (d->Co / 64) + splits - 1) / splits;
+        } else {
+            p.ncls = ncls;
+            p.M = maxM;
+            p.ntaps = ntap;
+        }
+        rc = vc_launch_igemm(p, 0, S(stream));
+        if (rc) return rc;
+    }
     if (splits > 1)
         return vc_ew_splitk_finalize((const float*)workspace, splits, (long long)dx_e, dx, accumulate, nullptr,
                                      (long)(dx_e / d->Ci), d->Ci, S(stream));

@@ -57,6 +57,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * BM;
     const int co0 = blockIdx.y * BCO;
+    // output geometry: the launch's own, or that of this block's class
+    int M = p.M, Ta = p.Ta, Ha = p.Ha, Wa = p.Wa, out_base = p.out_base, tap0 = 0, ntaps = p.ntaps;
+    int zsplit = blockIdx.z, cps = p.cps;
+    VcFastDiv dWa = p.dWa, dHa = p.dHa, dTa = p.dTa;
+    if (MODE == 0 && p.ncls > 1) {
+        const int zs = p.splits > 1 ? p.splits : 1;
+        const int c = blockIdx.z / zs;
+        zsplit = blockIdx.z - c * zs;
+        M = p.cls[c].M, Ta = p.cls[c].Ta, Ha = p.cls[c].Ha, Wa = p.cls[c].Wa;
+        dWa = p.cls[c].dWa, dHa = p.cls[c].dHa, dTa = p.cls[c].dTa;
+        out_base = p.cls[c].out_base, tap0 = p.cls[c].tap0, ntaps = p.cls[c].ntaps;
+        cps = (ntaps * (p.Cs >> 6) + zs - 1) / zs;
+        if (m0 >= M) return;  // the grid is sized for the largest class
+    }
 
     // ---- per-row geometry, one row per thread, staged in buffer 1 (unused until the first prefetch)
     int* sRowBase = (int*)(smem + Cfg::BUF_BYTES);
@@ -66,18 +80,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
         const int m = m0 + r;
         int base = 0, ooff = -1;
         unsigned mask = 0;
-        if (m < p.M) {
-            unsigned t1 = vc_div((unsigned)m, p.dWa);
-            int aw = m - (int)t1 * p.Wa;
-            unsigned t2 = vc_div(t1, p.dHa);
-            int ah = (int)t1 - (int)t2 * p.Ha;
-            unsigned n = vc_div(t2, p.dTa);
-            int at = (int)t2 - (int)n * p.Ta;
+        if (m < M) {
+            unsigned t1 = vc_div((unsigned)m, dWa);
+            int aw = m - (int)t1 * Wa;
+            unsigned t2 = vc_div(t1, dHa);
+            int ah = (int)t1 - (int)t2 * Ha;
+            unsigned n = vc_div(t2, dTa);
+            int at = (int)t2 - (int)n * Ta;
             const int s_t = at * p.st, s_h = ah * p.sh, s_w = aw * p.sw;
             base = ((((int)n * p.Ts + s_t) * p.Hs + s_h) * p.Ws + s_w) * p.Cs;
             if (MODE == 0) {
-                for (int i = 0; i < p.ntaps; ++i) {
-                    const int tt = s_t + p.taps[i].ot, hh = s_h + p.taps[i].oh, ww = s_w + p.taps[i].ow;
+                for (int i = 0; i < ntaps; ++i) {
+                    const int tt = s_t + p.taps[tap0 + i].ot, hh = s_h + p.taps[tap0 + i].oh, ww = s_w + p.taps[tap0 + i].ow;
                     const bool ok = (unsigned)tt < (unsigned)p.Ts && (unsigned)hh < (unsigned)p.Hs &&
                                     (unsigned)ww < (unsigned)p.Ws;
                     mask |= ok ? (1u << i) : 0u;
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
             } else {
                 mask = 0xffffffffu;
             }
-            ooff = p.out_base + (int)n * p.out_n + at * p.out_t + ah * p.out_h + aw * p.out_w;
+            ooff = out_base + (int)n * p.out_n + at * p.out_t + ah * p.out_h + aw * p.out_w;
         }
         sRowBase[r] = base;
         sRowMask[r] = mask;
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
     __syncthreads();  // the row table has been consumed; buffer 1 may be overwritten
 
     const int cpt = (MODE == 0) ? (p.Cs >> 6) : 1;               // chunks per tap
-    const int nchunks = (MODE == 0) ? p.ntaps * cpt : (p.Kw >> 6);
+    const int nchunks = (MODE == 0) ? ntaps * cpt : (p.Kw >> 6);
     const gptr_t zero = (gptr_t)vc_zero_page;
 
     auto issue_chunk = [&](int ti, int c0, int chunk, int buf) {
@@ -127,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
         char* bX = bW + BCO * ROWB;
         int soff, woff;
         if (MODE == 0) {
-            soff = p.taps[ti].src_off + c0;
-            woff = p.taps[ti].wk_off + c0;
+            soff = p.taps[tap0 + ti].src_off + c0;
+            woff = p.taps[tap0 + ti].wk_off + c0;
         } else {
             // stem: K = 28 macro-taps (kt, a_h) x 48 contiguous elements (a_w, b_h, b_w, c)
             const int g = chunk * 8 + lslot;  // 8-element K group fetched by this lane
@@ -155,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
 
     int cbeg = 0, cend = nchunks;
     if (p.splits > 1) {
-        cbeg = blockIdx.z * p.cps;
-        cend = min(nchunks, cbeg + p.cps);
+        cbeg = zsplit * cps;
+        cend = min(nchunks, cbeg + cps);
     }
     int ti = 0, c0 = 0;
     if (MODE == 0) {
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
     const int cobase = co0 + wco * 64 + lg * 4;
 
     if (p.partial != nullptr) {
-        float* slab = p.partial + (size_t)blockIdx.z * p.partial_stride;
+        float* slab = p.partial + (size_t)zsplit * p.partial_stride;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             if (ooff[b] < 0) continue;
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
 template <int BCO, int BM, int MODE>
 int launch_igemm(const VcIgemmParams& p, hipStream_t stream) {
     using Cfg = IgemmCfg<BCO, BM>;
-    dim3 grid((p.M + BM - 1) / BM, p.Cn / BCO, p.splits > 1 ? p.splits : 1);
+    dim3 grid((p.M + BM - 1) / BM, p.Cn / BCO, (p.splits > 1 ? p.splits : 1) * (p.ncls > 1 ? p.ncls : 1));
     (void)hipGetLastError();  // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL((igemm_kernel<BCO, BM, MODE>), grid, dim3(256), Cfg::LDS_BYTES, stream, p);
     const hipError_t e = hipGetLastError();
@@ -300,7 +314,14 @@ int vc_launch_igemm(const VcIgemmParams& p, int mode, hipStream_t stream) {
         vc_set_error("igemm: channels must be multiples of 64 (Cn=%d Cs=%d Kw=%d)", p.Cn, p.Cs, p.Kw);
         return -2;
     }
-    if (mode == 0 && (p.ntaps < 1 || p.ntaps > 32)) {
+    if (mode == 0 && p.ncls > 1) {
+        int tot = 0;
+        for (int c = 0; c < p.ncls; ++c) tot += p.cls[c].ntaps;
+        if (p.ncls > 8 || tot > 32) {
+            vc_set_error("igemm: %d classes with %d taps do not fit one launch", p.ncls, tot);
+            return -2;
+        }
+    } else if (mode == 0 && (p.ntaps < 1 || p.ntaps > 32)) {
         vc_set_error("igemm: ntaps=%d out of range", p.ntaps);
         return -2;
     }

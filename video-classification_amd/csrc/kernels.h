@@ -19,6 +19,15 @@ struct VcIgemmParams {
     int splits, cps;
     float* partial;
     long long partial_stride;
+    // several output classes in one launch (the stride-parity classes of a strided dgrad): blockIdx.z =
+    // class * max(splits, 1) + split; class c has its own output geometry and taps [tap0, tap0 + ntaps).
+    // ncls <= 1: the single geometry above.
+    int ncls;
+    struct Class {
+        int M, Ta, Ha, Wa;
+        VcFastDiv dWa, dHa, dTa;
+        int out_base, tap0, ntaps;
+    } cls[8];
     VcTap taps[32];
 };
 
