@@ -241,13 +241,33 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 }
 
 // dw += sum over slabs (deterministic split-K reduction of the weight gradient)
+// 64 float4 positions x 4 slab phases per block: phase q sums slabs q, q+4, ... (independent loads in flight),
+// the four partial sums are combined through LDS in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_wgrad_kernel(const float* __restrict__ slabs, int splits,
                                                                   long long stride, float* __restrict__ dw, long n4) {
-    const long step = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step) {
-        f32x4 s = ((const f32x4*)dw)[i];
-        for (int z = 0; z < splits; ++z) s += ((const f32x4*)(slabs + (size_t)z * stride))[i];
-        ((f32x4*)dw)[i] = s;
+    __shared__ f32x4 part[3][64];
+    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 64 + l;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+        int z = q;
+        for (; z + 4 < splits; z += 8) {
+            s += ((const f32x4*)(slabs + (size_t)z * stride))[i];
+            s1 += ((const f32x4*)(slabs + (size_t)(z + 4) * stride))[i];
+        }
+        if (z < splits) s += ((const f32x4*)(slabs + (size_t)z * stride))[i];
+        s += s1;
+    }
+    if (q > 0) part[q - 1][l] = s;
+    __syncthreads();
+    if (q == 0 && i < n4) {
+        s += part[0][l];
+        s += part[1][l];
+        s += part[2][l];
+        f32x4 o = ((const f32x4*)dw)[i];
+        o += s;
+        ((f32x4*)dw)[i] = o;
     }
 }
 
@@ -948,7 +968,7 @@ int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, hipStream_t s) {
-    VC_LAUNCH(splitk_reduce_wgrad_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, slabs, splits, stride, dw, n / 4);
+    VC_LAUNCH(splitk_reduce_wgrad_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, slabs, splits, stride, dw, n / 4);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_bwd_finalize(const float* sums, int C, float count, float* coef, float* dgamma, float* dbeta,

@@ -14,12 +14,13 @@
 // for wave kt; each plane = RH+3 padded rows, one contiguous global range, filled by LDS-DMA), two dY chunks
 // (LDS-DMA, 16-byte slots XOR-swizzled on the source side so that the transposing reads are conflict-free at a
 // 128-byte pitch) and a per-row offset table.  One barrier per frame.
-// Each workgroup ends by storing its 64 x 1344 partial into its own fp32 slab; a second kernel sums the slabs.
+// Each workgroup ends by storing its 64 x 1344 partial into its own fp32 slab; the split-K reduce kernel sums them.
 #include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
 #include "kernels.h"
+#include "elementwise.h"
 
 namespace {
 
@@ -158,18 +159,6 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2
         }
 }
 
-// dws[i] += sum over the workgroups' slabs
-__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslabs,
-                                                               float* __restrict__ dws) {
-    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= 64 * 1344) return;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < nslabs; ++g) s += *(const f32x4*)(slabs + (size_t)g * (64 * 1344) + i);
-    f32x4 o = *(f32x4*)(dws + i);
-    o += s;
-    *(f32x4*)(dws + i) = o;
-}
-
 }  // namespace
 
 // Geometry / plan.  Returns 0 when the image-resident form does not apply (then the generic kernel runs).
@@ -232,11 +221,11 @@ int vc_launch_stem_wgrad(VcStemWgradParams& p, float* dws, hipStream_t stream) {
     }
     (void)hipGetLastError();
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(p.grid), dim3(NWAVE * 64), p.lds_bytes, stream, p);
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * 1344 / 4 + 255) / 256), dim3(256), 0, stream, p.slabs, p.grid, dws);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         vc_set_error("stem wgrad launch failed: %s", hipGetErrorString(e));
         return -1;
     }
-    return 0;
+    // dws += sum of the workgroups' slabs
+    return vc_ew_splitk_reduce_wgrad(p.slabs, p.grid, (long long)64 * 1344, dws, 64L * 1344, stream);
 }
