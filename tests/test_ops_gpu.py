@@ -60,6 +60,9 @@ CONV_CASES = [
     (8, 256, 2, 7, 7, 256, 3, 1, 1),   # split-K forward / dgrad (few tiles, long K)
     (8, 128, 4, 14, 14, 256, 3, 2, 1), # split-K over stride-parity classes
     (16, 512, 1, 4, 4, 512, 3, 1, 1),
+    (4, 256, 2, 7, 7, 512, 3, 2, 1),   # T 2 -> 1: the first temporal tap only sees padding (dead-tap pruning)
+    (2, 64, 3, 1, 5, 64, 3, 1, 1),     # H = 1: six of nine (kh, kw) rows of taps are dead
+    (2, 128, 1, 2, 2, 128, 3, 2, 1),   # 1 x 2 x 2 -> 1 x 1 x 1
 ]
 
 

@@ -75,7 +75,30 @@ int vc_conv3d_out_dims(const vc_conv3d_desc* d, int32_t* To, int32_t* Ho, int32_
     return 0;
 }
 
-static int fwd_nchunks(const vc_conv3d_desc* d) { return d->kt * d->kh * d->kw * (d->Ci / 64); }
+// A tap that reads the zero padding from EVERY output position (its offset along some axis never lands inside
+// the input, e.g. the outer temporal taps once T has shrunk to 1) is dropped from the tap tables of all three
+// passes: the products it would add are exact zeros, so results are unchanged; its weight gradient stays 0.
+static bool axis_live(int a, int p, int s, int in, int out) {
+    for (int o = 0; o < out; ++o) {
+        const int i = o * s - p + a;
+        if (i >= 0 && i < in) return true;
+    }
+    return false;
+}
+static bool tap_live(const vc_conv3d_desc* d, int To, int Ho, int Wo, int a, int b, int c) {
+    return axis_live(a, d->pt, d->st, d->Ti, To) && axis_live(b, d->ph, d->sh, d->Hi, Ho) &&
+           axis_live(c, d->pw, d->sw, d->Wi, Wo);
+}
+static int live_taps(const vc_conv3d_desc* d) {
+    const int To = (d->Ti + 2 * d->pt - d->kt) / d->st + 1, Ho = (d->Hi + 2 * d->ph - d->kh) / d->sh + 1,
+              Wo = (d->Wi + 2 * d->pw - d->kw) / d->sw + 1;
+    int n = 0;
+    for (int a = 0; a < d->kt; ++a)
+        for (int b = 0; b < d->kh; ++b)
+            for (int c = 0; c < d->kw; ++c) n += tap_live(d, To, Ho, Wo, a, b, c) ? 1 : 0;
+    return n;
+}
+static int fwd_nchunks(const vc_conv3d_desc* d) { return live_taps(d) * (d->Ci / 64); }
 
 // stride 1, "same" padding, more than one tap, every tap within one plane / row / column of the output
 // position: served by the halo kernel (halo_conv.hip)
@@ -94,34 +117,49 @@ static bool wgrad9_ok(const vc_conv3d_desc* d) {
     return !off && d->kt == 3 && d->kh == 3 && d->kw == 3 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 1 &&
            d->ph == 1 && d->pw == 1;
 }
+// A tap of a stride-1 conv whose offset along an axis is at least the extent of that axis only ever reads the zero
+// padding (e.g. the two outer temporal taps when T == 1, as in layer4 at 16-frame clips): it is dropped from the
+// tap table.  The result is unchanged (those products are exact zeros), the work is not done.
+static bool halo_tap_live(const vc_conv3d_desc* d, int a, int b, int c) {
+    return tap_live(d, d->Ti, d->Hi, d->Wi, a, b, c);  // stride 1, "same" padding: output dims = input dims
+}
+static int halo_ntaps(const vc_conv3d_desc* d) {
+    int n = 0;
+    for (int a = 0; a < d->kt; ++a)
+        for (int b = 0; b < d->kh; ++b)
+            for (int c = 0; c < d->kw; ++c) n += halo_tap_live(d, a, b, c) ? 1 : 0;
+    return n;
+}
 static int halo_plan(const vc_conv3d_desc* d, bool dgrad, VcHaloPlan* plan) {
-    return vc_halo_plan(d->N * d->Ti, d->Ti, d->Hi, d->Wi, dgrad ? d->Co : d->Ci, dgrad ? d->Ci : d->Co, d->kt * d->kh * d->kw,
-                        plan);
+    return vc_halo_plan(d->N * d->Ti, d->Ti, d->Hi, d->Wi, dgrad ? d->Co : d->Ci, dgrad ? d->Ci : d->Co, halo_ntaps(d), plan);
 }
 static void halo_fill(VcHaloParams& p, const vc_conv3d_desc* d, bool dgrad) {
     memset(&p, 0, sizeof(p));
     p.NP = d->N * d->Ti, p.T = d->Ti, p.H = d->Hi, p.W = d->Wi;
     p.Cs = dgrad ? d->Co : d->Ci;
     p.Cn = dgrad ? d->Ci : d->Co;
-    p.ntaps = d->kt * d->kh * d->kw;
-    p.Kw = p.ntaps * p.Cs;
-    int i = 0;
+    p.Kw = d->kt * d->kh * d->kw * p.Cs;
+    int i = 0, n = 0;
     for (int a = 0; a < d->kt; ++a)
         for (int b = 0; b < d->kh; ++b)
             for (int c = 0; c < d->kw; ++c, ++i) {
-                VcTap& t = p.taps[i];
+                if (!halo_tap_live(d, a, b, c)) continue;
+                VcTap& t = p.taps[n++];
                 // forward: source = out + (a - p); data gradient: source (in dy) = in + (p - a)
                 t.ot = (short)(dgrad ? d->pt - a : a - d->pt);
                 t.oh = (short)(dgrad ? d->ph - b : b - d->ph);
                 t.ow = (short)(dgrad ? d->pw - c : c - d->pw);
                 t.wk_off = i * p.Cs;
             }
+    p.ntaps = n;
 }
 
 // largest tap count over the stride-parity classes of the data gradient
 static int dgrad_max_taps(const vc_conv3d_desc* d, bool* has_empty_class) {
     int best = 0;
     bool empty = false;
+    const int To = (d->Ti + 2 * d->pt - d->kt) / d->st + 1, Ho = (d->Hi + 2 * d->ph - d->kh) / d->sh + 1,
+              Wo = (d->Wi + 2 * d->pw - d->kw) / d->sw + 1;
     for (int rt = 0; rt < d->st; ++rt)
         for (int rh = 0; rh < d->sh; ++rh)
             for (int rw = 0; rw < d->sw; ++rw) {
@@ -131,7 +169,7 @@ static int dgrad_max_taps(const vc_conv3d_desc* d, bool* has_empty_class) {
                         for (int c = 0; c < d->kw; ++c)
                             if ((((rt + d->pt - a) % d->st) + d->st) % d->st == 0 &&
                                 (((rh + d->ph - b) % d->sh) + d->sh) % d->sh == 0 &&
-                                (((rw + d->pw - c) % d->sw) + d->sw) % d->sw == 0)
+                                (((rw + d->pw - c) % d->sw) + d->sw) % d->sw == 0 && tap_live(d, To, Ho, Wo, a, b, c))
                                 ++cnt;
                 if (cnt == 0) empty = true;
                 if (cnt > best) best = cnt;
@@ -167,13 +205,13 @@ size_t vc_conv3d_workspace_bytes(const vc_conv3d_desc* d, int32_t op) {
     }
     if (op == 2 && wgrad9_ok(d)) {
         int rps;
-        const int s = vc_wgrad9_plan((long)d->N * d->Ti * d->Hi * d->Wi, d->Wi, d->Ci, d->Co, &rps);
+        const int s = vc_wgrad9_plan((long)d->N * d->Ti * d->Hi * d->Wi, d->Wi, d->Ci, d->Co, d->Ti > 1 ? 3 : 1, &rps);
         if (s > 0) return s > 1 ? (size_t)s * d->Co * 27 * d->Ci * 4 : 0;
     }
     if (op == 2) {
         int rps;
         const int taps = d->kt * d->kh * d->kw;
-        const int s = vc_wgrad_splits(d->N * To * Ho * Wo, d->Co, taps * (d->Ci / 64), &rps);
+        const int s = vc_wgrad_splits(d->N * To * Ho * Wo, d->Co, live_taps(d) * (d->Ci / 64), &rps);
         return s > 1 ? (size_t)s * d->Co * taps * d->Ci * 4 : 0;
     }
     return 0;
@@ -197,20 +235,21 @@ int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y
     p.dWa = vc_make_fastdiv(Wo), p.dHa = vc_make_fastdiv(Ho), p.dTa = vc_make_fastdiv(To);
     p.Ts = d->Ti, p.Hs = d->Hi, p.Ws = d->Wi, p.Cs = d->Ci;
     p.st = d->st, p.sh = d->sh, p.sw = d->sw;
-    p.ntaps = d->kt * d->kh * d->kw;
-    p.Kw = p.ntaps * d->Ci;
+    p.Kw = d->kt * d->kh * d->kw * d->Ci;
     p.Cn = d->Co;
     p.out_w = d->Co, p.out_h = Wo * d->Co, p.out_t = Ho * Wo * d->Co, p.out_n = To * Ho * Wo * d->Co, p.out_base = 0;
     p.accumulate = 0;
-    int i = 0;
+    int i = 0, nlive = 0;
     for (int a = 0; a < d->kt; ++a)
         for (int b = 0; b < d->kh; ++b)
             for (int c = 0; c < d->kw; ++c, ++i) {
-                VcTap& t = p.taps[i];
+                if (!tap_live(d, To, Ho, Wo, a, b, c)) continue;
+                VcTap& t = p.taps[nlive++];
                 t.ot = (short)(a - d->pt), t.oh = (short)(b - d->ph), t.ow = (short)(c - d->pw);
                 t.src_off = ((t.ot * d->Hi + t.oh) * d->Wi + t.ow) * d->Ci;
                 t.wk_off = i * d->Ci;
             }
+    p.ntaps = nlive;
     const int splits = vc_igemm_splits(p.M, p.Cn, fwd_nchunks(d));
     const size_t out_e = (size_t)p.M * d->Co;
     if (splits > 1 && workspace != nullptr && ws_bytes >= (size_t)splits * out_e * 4) {
@@ -284,7 +323,7 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
                         for (int b = 0; b < d->kh; ++b)
                             for (int c = 0; c < d->kw; ++c)
                                 if (posmod(rt + d->pt - a, d->st) == 0 && posmod(rh + d->ph - b, d->sh) == 0 &&
-                                    posmod(rw + d->pw - c, d->sw) == 0)
+                                    posmod(rw + d->pw - c, d->sw) == 0 && tap_live(d, To, Ho, Wo, a, b, c))
                                     ++cnt;
                     if (cnt == 0) need_zero = true;
                 }
@@ -338,6 +377,7 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
                         for (int cc = 0; cc < d->kw; ++cc, ++i) {
                             const int nt = rt + d->pt - a, nh = rh + d->ph - b, nw = rw + d->pw - cc;
                             if (posmod(nt, d->st) || posmod(nh, d->sh) || posmod(nw, d->sw)) continue;
+                            if (!tap_live(d, To, Ho, Wo, a, b, cc)) continue;  // pairs no output with a real input
                             VcTap& t = p.taps[c.tap0 + n++];
                             t.ot = (short)floordiv(nt, d->st), t.oh = (short)floordiv(nh, d->sh),
                             t.ow = (short)floordiv(nw, d->sw);
@@ -388,7 +428,7 @@ int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, floa
     VC_REQUIRE(x && dy && dw, "conv3d_wgrad: null pointer");
     if (wgrad9_ok(d)) {
         int rps9 = 0;
-        const int s9 = vc_wgrad9_plan((long)d->N * d->Ti * d->Hi * d->Wi, d->Wi, d->Ci, d->Co, &rps9);
+        const int s9 = vc_wgrad9_plan((long)d->N * d->Ti * d->Hi * d->Wi, d->Wi, d->Ci, d->Co, d->Ti > 1 ? 3 : 1, &rps9);
         if (s9 > 0) {
             VcWgrad9Params q;
             memset(&q, 0, sizeof(q));
@@ -396,6 +436,7 @@ int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, floa
             q.NP = d->N * d->Ti, q.T = d->Ti, q.H = d->Hi, q.W = d->Wi;
             q.Cs = d->Ci, q.Co = d->Co, q.Kw = 27 * d->Ci;
             q.rows_per_split = rps9, q.splits = s9;
+            q.dt0 = d->Ti > 1 ? 0 : 1, q.ndt = d->Ti > 1 ? 3 : 1;  // T == 1: the dt = -1 / +1 taps only see padding
             const size_t dw_e9 = (size_t)d->Co * q.Kw;
             if (s9 > 1 && workspace != nullptr && ws_bytes >= (size_t)s9 * dw_e9 * 4) {
                 q.partial = (float*)workspace;
@@ -417,20 +458,21 @@ int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, floa
     p.dWa = vc_make_fastdiv(Wo), p.dHa = vc_make_fastdiv(Ho), p.dTa = vc_make_fastdiv(To);
     p.Ts = d->Ti, p.Hs = d->Hi, p.Ws = d->Wi, p.Cs = d->Ci;
     p.st = d->st, p.sh = d->sh, p.sw = d->sw;
-    p.ntaps = d->kt * d->kh * d->kw;
-    p.Kw = p.ntaps * d->Ci;
+    p.Kw = d->kt * d->kh * d->kw * d->Ci;
     p.Co = d->Co;
-    int i = 0;
+    int i = 0, nlive = 0;
     for (int a = 0; a < d->kt; ++a)
         for (int b = 0; b < d->kh; ++b)
             for (int c = 0; c < d->kw; ++c, ++i) {
-                VcTap& t = p.taps[i];
+                if (!tap_live(d, To, Ho, Wo, a, b, c)) continue;  // its weight gradient is exactly 0: dw is left alone
+                VcTap& t = p.taps[nlive++];
                 t.ot = (short)(a - d->pt), t.oh = (short)(b - d->ph), t.ow = (short)(c - d->pw);
                 t.src_off = ((t.ot * d->Hi + t.oh) * d->Wi + t.ow) * d->Ci;
                 t.wk_off = i * d->Ci;
             }
+    p.ntaps = nlive;
     int rps;
-    const int splits = vc_wgrad_splits(p.M, p.Co, p.ntaps * (d->Ci / 64), &rps);
+    const int splits = vc_wgrad_splits(p.M, p.Co, live_taps(d) * (d->Ci / 64), &rps);
     const size_t dw_e = (size_t)d->Co * p.Kw;
     if (splits > 1 && workspace != nullptr && ws_bytes >= (size_t)splits * dw_e * 4) {
         p.partial = (float*)workspace;

@@ -83,10 +83,11 @@ struct VcWgrad9Params {
     long long partial_stride;
     int NP, T, H, W, Cs, Co, Kw;
     int rows_per_split, splits;
+    int dt0, ndt;    // temporal offsets computed: dt = dt0 - 1 .. dt0 + ndt - 2 (all three, or only dt = 0 when T == 1)
     long long* dbg;  // nullable: per-workgroup phase clocks (tuning aid)
     VcFastDiv dHW, dT, dW;
 };
-int vc_wgrad9_plan(long M, int W, int Cs, int Co, int* rows_per_split);  // splits; 0 = geometry not supported
+int vc_wgrad9_plan(long M, int W, int Cs, int Co, int ndt, int* rows_per_split);  // splits; 0 = geometry not supported
 int vc_launch_wgrad9(VcWgrad9Params& p, hipStream_t stream);
 
 // stem_wgrad.hip: stem weight gradient with the raw space-to-depth rows resident in LDS (persistent workgroups)

@@ -37,8 +37,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nci = p.Cs >> 6;
-    const int dtg = blockIdx.x / nci;          // 0..2  -> dt = dtg - 1
-    const int cic = blockIdx.x - dtg * nci;
+    const int dtg = p.dt0 + blockIdx.x / nci;  // 0..2  -> dt = dtg - 1
+    const int cic = blockIdx.x % nci;
     const int coc = blockIdx.y;
     const int HW = p.H * p.W;
     const int XR = CH + 2 * p.W + 2;            // image rows per chunk
@@ -251,9 +251,9 @@ static int wgrad9_lds(int W) {
     return lds <= 160 * 1024 ? lds : 0;
 }
 
-int vc_wgrad9_plan(long M, int W, int Cs, int Co, int* rows_per_split) {
+int vc_wgrad9_plan(long M, int W, int Cs, int Co, int ndt, int* rows_per_split) {
     if (wgrad9_lds(W) == 0) return 0;
-    const long tiles = 3L * (Cs / 64) * (Co / 64);
+    const long tiles = (long)ndt * (Cs / 64) * (Co / 64);
     static const long target = getenv("VC_WGRAD9_TARGET") ? atol(getenv("VC_WGRAD9_TARGET")) : 256;
     long splits = (target + tiles / 2) / tiles;
     const long maxs = (M + 4 * CH - 1) / (4 * CH);  // at least 4 chunks per slice
@@ -285,7 +285,8 @@ int vc_launch_wgrad9(VcWgrad9Params& p, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)wgrad9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set[dev] = true;
     }
-    dim3 grid(3 * (p.Cs / 64), p.Co / 64, p.splits);
+    if (p.ndt < 1 || p.ndt > 3) p.dt0 = 0, p.ndt = 3;
+    dim3 grid(p.ndt * (p.Cs / 64), p.Co / 64, p.splits);
     (void)hipGetLastError();
     hipLaunchKernelGGL(wgrad9_kernel, grid, dim3(NT), lds, stream, p);
     const hipError_t e = hipGetLastError();
