@@ -45,6 +45,7 @@ class GradBucketReducer:
             last_key, off, n = ranges[-1]
             self.buckets.append([cur_start, off + n, cur_n])
         self.comm_stream = torch.cuda.Stream() if flat.is_cuda else None
+        self.producer_streams = lambda: ()  # extra streams that write gradients (the engine's weight-gradient stream)
         self.reset()
 
     def reset(self):
@@ -69,10 +70,17 @@ class GradBucketReducer:
         start, end, _ = self.buckets[b]
         seg = self.flat[start:end]
         if self.flat.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            # the bucket's gradients were issued on the current stream and, for conv weights, on the engine's side
+            # stream: the all-reduce waits for everything issued so far on each of them
+            evs = []
+            cur = torch.cuda.current_stream()
+            for st in {cur, *[x for x in self.producer_streams() if x is not None]}:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                evs.append(ev)
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
+                for ev in evs:
+                    self.comm_stream.wait_event(ev)
                 if self.backend == "nccl":
                     w = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
                 else:
@@ -127,6 +135,7 @@ class DataParallel3D(torch.nn.Module):
         if self.reducer is None or self.reducer.flat is not eng.flat_grad:
             ranges = [(id(p), off, n) for p, off, n in eng.grad_ranges]
             self.reducer = GradBucketReducer(eng.flat_grad, ranges, self.group, self.bucket_bytes)
+            self.reducer.producer_streams = lambda: (eng._side,)
         return self.reducer
 
     def _on_ready(self, p):

@@ -15,8 +15,11 @@ import torch
 from . import ops
 from .capi import VC_STAT_REPLICAS, Vc3dError
 
+import os
+
 BF16 = torch.bfloat16
 F32 = torch.float32
+SIDE_WGRAD = os.environ.get("VC_WGRAD_SIDE_STREAM", "1") != "0"  # weight gradients on a side stream (engine._wgrad)
 
 
 def _triple(v):
@@ -80,6 +83,7 @@ class R3DEngine:
         self.param_epoch = 0     # bumped by a fused optimizer step (memory changed behind torch's back)
         self.grad_views = None
         self.grad_ready_cb = None  # set by the data-parallel wrapper: cb(param)
+        self._side = None          # side stream of the weight-gradient launches (see _wgrad)
         self.backward_done_cb = None
         self._stem_scratch = None
         self.trace = None  # tests set this to {} to record every intermediate tensor per layer
@@ -213,6 +217,26 @@ class R3DEngine:
             for p in params:
                 self.grad_ready_cb(p)
 
+    def _wgrad(self, d, h, dy, conv):
+        """weight gradient of one conv.  Nothing downstream in backward consumes it, so it is issued on a side
+        stream behind an event: the dependent chain of the main stream (dgrad -> BN backward reduce / finalize /
+        apply of the next layer, mostly short bandwidth- or latency-bound kernels) overlaps with the MFMA-bound
+        weight-gradient kernels instead of waiting behind them.  Joined at the end of backward."""
+        if not SIDE_WGRAD or self.trace is not None:
+            ops.conv3d_wgrad(d, h, dy, self._gphys(conv.weight))
+            self._ready(conv.weight)
+            return
+        if self._side is None or self._side.device != dy.device:
+            self._side = torch.cuda.Stream(device=dy.device)
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            ops.conv3d_wgrad(d, h, dy, self._gphys(conv.weight))
+            self._ready(conv.weight)  # a bucket all-reduce must wait for THIS stream: the event is recorded here
+        dy.record_stream(self._side)  # dy is dropped right after the dgrad on the main stream
+        h.record_stream(self._side)
+
     # ------------------------------------------------------------------ forward
     def _bn_params(self, cb, stats, count, training):
         bn = cb.bn
@@ -323,8 +347,7 @@ class R3DEngine:
             dy, gres = ops.bn_bwd(y, g, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias), mask=1,
                                   aux=out, want_g=True, sums=sums_pool.take(cb.Co))
             self._ready(cb.bn.weight, cb.bn.bias)
-            ops.conv3d_wgrad(d, h, dy, self._gphys(cb.conv.weight))
-            self._ready(cb.conv.weight)
+            self._wgrad(d, h, dy, cb.conv)
             _, wd = cb.weights()
             dz = ops.conv3d_dgrad(d, dy, wd)
             self._t(cb.name, dz=g, dy=dy, gres=gres, dx=dz, dx_base=None)
@@ -342,16 +365,14 @@ class R3DEngine:
                     dyd, _ = ops.bn_bwd(yd, gres, prmd, ds.Co, self.gview(ds.bn.weight), self.gview(ds.bn.bias),
                                         mask=0, sums=sums_pool.take(ds.Co))
                     self._ready(ds.bn.weight, ds.bn.bias)
-                    ops.conv3d_wgrad(dd, xin, dyd, self._gphys(ds.conv.weight))
-                    self._ready(ds.conv.weight)
+                    self._wgrad(dd, xin, dyd, ds.conv)
                     _, wdd = ds.weights()
                     dzd = gres
                     gres = ops.conv3d_dgrad(dd, dyd, wdd)
                     self._t(ds.name, dz=dzd, dy=dyd, dx=gres.clone() if self.trace is not None else None,
                             dx_base=None)
                     del dyd
-                ops.conv3d_wgrad(d, h, dy, self._gphys(cb.conv.weight))
-                self._ready(cb.conv.weight)
+                self._wgrad(d, h, dy, cb.conv)
                 _, wd = cb.weights()
                 dz_in = dz
                 if i == 0:
@@ -381,6 +402,8 @@ class R3DEngine:
         self._t("conv1", dy=dy0)
         ops.stem_wgrad(xs, dy0, N, T, H, W, st.Co, self._gphys(st.conv.weight), scratch=self._stem_scratch)
         self._ready(st.conv.weight)
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
         if self.backward_done_cb is not None:
             self.backward_done_cb()
 
