@@ -135,7 +135,9 @@ class DataParallel3D(torch.nn.Module):
         if self.reducer is None or self.reducer.flat is not eng.flat_grad:
             ranges = [(id(p), off, n) for p, off, n in eng.grad_ranges]
             self.reducer = GradBucketReducer(eng.flat_grad, ranges, self.group, self.bucket_bytes)
-            self.reducer.producer_streams = lambda: (eng._side,)
+            # gradients are written on the stream backward runs on (BatchNorm, head) and on the engine's side
+            # stream (conv weights); a ready callback may come from inside either stream's context
+            self.reducer.producer_streams = lambda: (eng._side, eng._main)
         return self.reducer
 
     def _on_ready(self, p):

@@ -84,6 +84,7 @@ class R3DEngine:
         self.grad_views = None
         self.grad_ready_cb = None  # set by the data-parallel wrapper: cb(param)
         self._side = None          # side stream of the weight-gradient launches (see _wgrad)
+        self._main = None          # the stream backward was issued on (what a bucket all-reduce must also wait for)
         self.backward_done_cb = None
         self._stem_scratch = None
         self.trace = None  # tests set this to {} to record every intermediate tensor per layer
@@ -335,6 +336,7 @@ class R3DEngine:
     def backward(self, saved, dfeat):
         """dfeat: fp32 [N][F].  Writes every backbone parameter gradient (accumulating)."""
         dev = dfeat.device
+        self._main = torch.cuda.current_stream()
         sums_pool = _StatsPool(sum(cb.Co for cb in self.all_convbn()), dev)
         shape = saved["final"][0]
         N, To, Ho, Wo, Cf = shape
