@@ -12,6 +12,13 @@ two extra objects:
   cpu_baseline : the oracle (stock torch.nn fp32 3D-ResNet-18, oracle/r3d_torch.py) timed on
                  this box's host cores on a bounded sample (config 1: batch 8), rank 0, N=1 only.
 """
+import os as _os
+
+# more hardware queues than HIP's default of 4: backward stream + weight-gradient stream + bucket stream + RCCL
+# (vc3d/ddp.py); must be set before the HIP runtime initialises
+if int(_os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8 and _os.environ.get("VC_KEEP_HW_QUEUES") != "1":
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
 import argparse
 import json
 import os

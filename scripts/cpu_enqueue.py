@@ -13,6 +13,12 @@ from utils.utils import create_optimizer
 cfg = config.clone(); cfg.MODEL.RESNET_TYPE = 18; cfg.MODEL.CLFDIM = 101; cfg.MODEL.INIT_WEIGHTS = False
 cfg.TRAIN.OPTIMIZER = "sgd"; cfg.TRAIN.LR = 0.001
 model = create_model(cfg, is_train=True).cuda(); crit = Loss(cfg).cuda(); opt = create_optimizer(cfg, model)
+if os.environ.get("VC_DDP_FORCE_COMM") == "1":  # one-rank RCCL rehearsal of the data-parallel wrapper
+    import torch.distributed as dist
+    from vc3d.ddp import DataParallel3D
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    model = DataParallel3D(model, bucket_mb=float(os.environ.get("VC_BUCKET_MB", "32")))
 x = torch.randn(64, 3, 16, 112, 112).to(torch.bfloat16).cuda(); y = torch.randint(0, 101, (64,)).cuda()
 model.train()
 def step():

@@ -12,6 +12,13 @@ backward (vc3d/ddp.py).  A plain `python train.py` runs one GPU.
 
 Overrides: KEY=VALUE pairs on the command line, e.g. TRAIN.END_EPOCH=1 MODEL.RESNET_TYPE=50.
 """
+import os as _os
+
+# more hardware queues than HIP's default of 4: backward stream + weight-gradient stream + bucket stream + RCCL
+# (vc3d/ddp.py); must be set before the HIP runtime initialises
+if int(_os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8 and _os.environ.get("VC_KEEP_HW_QUEUES") != "1":
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
 import os
 import sys
 

@@ -8,6 +8,13 @@ the views' logits before the argmax.  Forward only, eval-mode BatchNorm (running
 folded into one scale/shift per channel).  One process per GPU; accuracy counts are summed over
 ranks.  Overrides: KEY=VALUE pairs, plus CKPT=path for a checkpoint written by train.py.
 """
+import os as _os
+
+# more hardware queues than HIP's default of 4: backward stream + weight-gradient stream + bucket stream + RCCL
+# (vc3d/ddp.py); must be set before the HIP runtime initialises
+if int(_os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8 and _os.environ.get("VC_KEEP_HW_QUEUES") != "1":
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
 import os
 import sys
 

@@ -123,5 +123,13 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def cur_stream():
+    """raw hipStream_t of torch's current stream on the current device.  The private C accessors are ~20x
+    cheaper than torch.cuda.current_stream() (8 us per call, ~150 calls per training step)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
