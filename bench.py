@@ -161,10 +161,19 @@ def main():
             optimizer.step()
 
     # ---- warm-up; the last warm-up step times every conv launch to find the dominant kernel
+    # (that one step runs with the weight gradients on the main stream: event-bracketed times are exclusive kernel
+    # durations only when nothing runs beside the kernel; the timed region below keeps the two-stream overlap, and
+    # the dominant launch turns out to be a forward kernel, which has the GPU to itself either way)
+    import vc3d.engine as _eng
     for i in range(max(args.warmup, 1)):
-        if i == max(args.warmup, 1) - 1:
+        last = i == max(args.warmup, 1) - 1
+        if last:
+            torch.cuda.synchronize()
             ops.TIMER = ops.KernelTimer()
+            side, _eng.SIDE_WGRAD = _eng.SIDE_WGRAD, False
         step()
+        if last:
+            _eng.SIDE_WGRAD = side
     torch.cuda.synchronize()
     table = ops.TIMER.summary()
     ops.TIMER = None
