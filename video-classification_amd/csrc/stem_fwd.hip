@@ -11,8 +11,8 @@
 // Persistent workgroups of 7 waves.  Work unit = (sample, group of RH output rows, range of TR frames); frames
 // are processed in pairs: a chunk of RH x Wo <= 224 positions per frame, wave w owns positions [32w, 32w+32)
 // of both frames x all 64 co = 16 accumulator tiles.  The weights stream through LDS one temporal tap at a
-// time (64 x 192 bf16, 416-byte row pitch produced on the DMA's source side, double-buffered, one barrier per
-// tap); A = weights (so a lane ends with 4 consecutive channels of one position), B = image.
+// time (64 x 192 bf16, 416-byte row pitch produced on the DMA's source side, three tiles in flight with a counted
+// s_waitcnt vmcnt, one barrier per tap); A = weights (so a lane ends with 4 consecutive channels of one position), B = image.
 // Epilogue per frame pair: bf16 channels-last stores straight from the accumulators; BatchNorm sum / sum of
 // squares are kept in registers over the workgroup's whole share and leave as 128 atomics per workgroup.
 #include <stdlib.h>
@@ -35,9 +35,13 @@ constexpr int NWAVE = 7;
 constexpr int WPITCH = 416;          // bytes per weight row in LDS: 384 data + 32 pad (conflict-free ds_read_b128)
 constexpr int WPIECES = 26;          // 64 rows x 26 slots of 16 bytes = 26 pieces of 1 KiB
 constexpr int WBUF = WPIECES * 1024;
-constexpr int NSLOT = 10;            // plane ring: 8 planes of the current frame pair + 2 of the next
+constexpr int NSLOT = 8;             // plane ring: the 8 planes of a frame pair; the next pair's two new planes
+                                     // replace planes t, t+1 once temporal tap 1 is done with them
+constexpr int NWB = 3;               // weight tiles in flight: tap g is computed while g+1 and g+2 stream in
+constexpr int WPW = 4;               // weight DMA instructions per wave and tile (26 pieces + 2 dummies over 7 waves)
 constexpr int W_OFF = 0;
-constexpr int PL_OFF = 2 * WBUF;
+constexpr int DUMMY_OFF = NWB * WBUF;  // 1 KiB that the dummy DMA instructions land in
+constexpr int PL_OFF = NWB * WBUF + 1024;
 
 __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem_fwd_kernel(
     const VcStemFwdParams p) {
@@ -86,14 +90,19 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2
             __builtin_amdgcn_global_load_lds(src, (lptr_t)(dst + pc * 1024), 16, 0, 0);
         }
     };
+    // every wave issues exactly WPW instructions per tile (the last two go to a dummy KiB), so that a counted
+    // s_waitcnt vmcnt(WPW) means "everything but the youngest tile has landed" in every wave
     auto issue_w = [&](int kt, int buf) {
         char* dst = smem + W_OFF + buf * WBUF;
-        for (int pc = wave; pc < WPIECES; pc += NWAVE) {
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int pc = wave + NWAVE * i;
             const unsigned S = (unsigned)(pc * 64 + lane);
             const unsigned row = (S * 2521u) >> 16;  // S / 26 for S < 1664
             const unsigned part = S - row * 26u;
-            const gptr_t src = part < 24u ? (gptr_t)(p.ws + ((size_t)row * 1344 + kt * 192 + part * 8)) : zero;
-            __builtin_amdgcn_global_load_lds(src, (lptr_t)(dst + pc * 1024), 16, 0, 0);
+            const bool real = pc < WPIECES;
+            const gptr_t src = real && part < 24u ? (gptr_t)(p.ws + ((size_t)row * 1344 + kt * 192 + part * 8)) : zero;
+            __builtin_amdgcn_global_load_lds(src, (lptr_t)(real ? dst + pc * 1024 : smem + DUMMY_OFF), 16, 0, 0);
         }
     };
 
@@ -107,8 +116,10 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2
         const int cpv = min(p.RH, p.Ho - h0) * p.Wo;  // valid positions of this row group
         __syncthreads();  // the previous unit's last reads are done: ring and weight buffers may be refilled
         for (int tp = t0; tp < t0 + 8; ++tp) issue_plane(n, tp, h0);
+        const int nsteps = ((t1 - t0 + 1) >> 1) * 7;  // temporal-tap steps of this unit
         issue_w(0, 0);
-        int wbuf = 0;
+        if (nsteps > 1) issue_w(1, 1);
+        int g = 0;  // step counter of the unit: weight tile of step g sits in buffer g % NWB
         for (int t = t0; t < t1; t += 2) {
             f32x4 acc[4][2][2];
 #pragma unroll
@@ -118,18 +129,23 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) acc[a][f][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-            for (int kt = 0; kt < 7; ++kt) {
-                __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): everything issued so far has landed
+            for (int kt = 0; kt < 7; ++kt, ++g) {
+                // tile g has landed once at most the younger tile g+1 is in flight; the step after the plane
+                // refill (kt == 3) and the unit's last step drain everything
+                if (kt == 3 || g + 1 >= nsteps) __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+                else __builtin_amdgcn_s_waitcnt(0x0074);                             // vmcnt(4) lgkmcnt(0)
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-#if !(VC_STEMF_ABLATE & 1)
-                if (kt < 6) issue_w(kt + 1, wbuf ^ 1);
-                else if (t + 2 < t1) issue_w(0, wbuf ^ 1);
-#endif
-                if (!(VC_STEMF_ABLATE & 2) && kt == 0 && t + 2 < t1) {  // the planes only the next pair needs, into the slots of planes t-2, t-1
+                const int wbuf = g % NWB;
+#if !(VC_STEMF_ABLATE & 2)
+                if (kt == 2 && t + 2 < t1) {  // planes t and t+1 are dead after tap 1: the next pair's new planes go there
                     issue_plane(n, t + 8, h0);
                     issue_plane(n, t + 9, h0);
                 }
+#endif
+#if !(VC_STEMF_ABLATE & 1)
+                if (g + 2 < nsteps) issue_w((kt + 2) % 7, (g + 2) % NWB);  // buffer of tile g-1, read one step ago
+#endif
                 const char* sW = smem + W_OFF + wbuf * WBUF + aoff;
                 const char* pl0 = smem + PL_OFF + ((t + kt) % NSLOT) * PLB;
                 const char* pl1 = smem + PL_OFF + ((t + 1 + kt) % NSLOT) * PLB;
@@ -151,7 +167,6 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2
                                 acc[a][f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[a][f][nt], 0, 0, 0);
                         }
                 }
-                wbuf ^= 1;
             }
             // ---- acc[a][f][nt][j] = Y[frame t+f][position mloc[nt]][co = a*16 + lg*4 + j]
 #pragma unroll
@@ -220,7 +235,7 @@ int vc_stem_fwd_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcSte
     double best_eff = 0.0;
     for (int RH = 1; RH <= Ho && RH * Wo <= NWAVE * 32; ++RH) {
         const int pieces = ((RH + 3) * RP + 1023) / 1024;
-        const long lds = 2L * WBUF + (long)NSLOT * pieces * 1024;
+        const long lds = (long)NWB * WBUF + 1024 + (long)NSLOT * pieces * 1024;
         if (lds > 160 * 1024) break;
         const int nhg = (Ho + RH - 1) / RH;
         const double eff = ((double)Ho * Wo / ((double)nhg * NWAVE * 32)) * ((double)RH / (RH + 1.0));
@@ -244,7 +259,7 @@ int vc_stem_fwd_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcSte
     }
     p.units = N * p.nhg * p.ntr;
     p.grid = p.units < target ? p.units : target;
-    p.lds_bytes = 2 * WBUF + NSLOT * p.plane_pieces * 1024;
+    p.lds_bytes = NWB * WBUF + 1024 + NSLOT * p.plane_pieces * 1024;
     *out = p;
     return 1;
 }
