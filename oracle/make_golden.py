@@ -24,6 +24,7 @@ What it writes, and what pins what:
       global average pool, Linear.  Inputs are stored with the outputs.
   r3d18_small.npz                 -- whole-net oracle R3D-18 on a seeded 4x3x8x64x64 batch (2 clips of 32x32 leave late BN layers with 2 values per channel: ill-conditioned):
       logits, loss, per-parameter gradient norms, BN running statistics after one step.
+  r3d18_full.npz                  -- the same at the bench geometry, 2x3x16x112x112, 101 classes: logits, loss, gradient norms.
 
 Inputs and weights that are too large to commit are regenerated from seeds; a SHA-256 of
 their bytes is stored so a test can tell "RNG stream changed" from "arithmetic changed".
@@ -204,6 +205,23 @@ def r3d18_small():
     print("r3d18_small loss %.6f" % float(loss))
 
 
+def r3d18_full():
+    """the bench geometry (16x112x112 clips, 101 classes) at batch 2: every kernel of the product path runs in the
+    regime it is tuned for (image-resident stem kernels at 56-wide rows, padded-halo convs, wgrad9, T = 1 in layer4)"""
+    model = init_weights_(R3DOracle(18, 101), 0).train()
+    x, y = synthetic_batch(2, 16, 112, 112, 101, 2468)
+    wsha = hashlib.sha256(b"".join(p.detach().numpy().tobytes() for p in model.parameters())).hexdigest()
+    logits = model(x)
+    loss = F.cross_entropy(logits, y)
+    loss.backward()
+    rec = {"x_sha": np.array(sha(x)), "w_sha": np.array(wsha), "y": y.numpy(), "logits": logits.detach().numpy(),
+           "loss": np.float64(float(loss))}
+    for n, p in model.named_parameters():
+        rec["gnorm/" + n] = np.float64(float(p.grad.double().norm()))
+    np.savez_compressed(os.path.join(OUT, "r3d18_full.npz"), **rec)
+    print("r3d18_full loss %.6f" % float(loss))
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("make_golden.py runs in the build container only (needs %s)" % REF)
@@ -214,6 +232,7 @@ def main():
     loss_ref()
     ops3d()
     r3d18_small()
+    r3d18_full()
 
 
 if __name__ == "__main__":
