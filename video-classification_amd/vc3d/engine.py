@@ -358,8 +358,10 @@ class R3DEngine:
             for i in range(len(cbs) - 2, -1, -1):
                 cb = cbs[i]
                 d, h, y, prm, z = recs[i]
-                dy, _ = ops.bn_bwd(y, dz, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias), mask=1,
-                                   aux=z, sums=sums_pool.take(cb.Co))
+                # BN -> ReLU with nothing in between: the ReLU mask is recomputed from y (scale * y + shift > 0,
+                # the forward's own expression) instead of reading the activation z a third tensor per pass
+                dy, _ = ops.bn_bwd(y, dz, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias), mask=2,
+                                   sums=sums_pool.take(cb.Co))
                 self._ready(cb.bn.weight, cb.bn.bias)
                 if i == 0 and ds is not None:
                     # downsample branch first so the first conv's dgrad can accumulate onto it
