@@ -137,9 +137,11 @@ int vc_maxpool3d_bwd(const vc_pool3d_desc* d, const void* dout, const uint8_t* a
 /* BatchNorm+ReLU backward THROUGH the max pool (the stem, reference backbone.py:146-148 in reverse): the
  * gradient entering BN+ReLU is gathered from the pooled gradient and the arg-max map on the fly instead of
  * being materialised by vc_maxpool3d_bwd.  `d` describes the pool (its input = y's geometry); ReLU mask
- * recomputed from y (mask mode 2).  Use with vc_bn_bwd_finalize in between. */
+ * recomputed from y (mask mode 2).  Use with vc_bn_bwd_finalize in between.  `pooled` (nullable) is the
+ * pool's own output from vc_maxpool3d_fwd with bn_params: the reduce then solves y at the arg-max from it
+ * instead of gathering y element by element (channels with |beta| > 16 |gamma| keep the gather). */
 int vc_bn_bwd_reduce_pooled(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
-                            const float* params, float* sums, void* stream);
+                            const void* pooled, const float* params, float* sums, void* stream);
 int vc_bn_bwd_apply_pooled(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
                            const float* params, const float* coef, void* dy, void* stream);
 int vc_gavgpool_fwd(const void* in, float* out, int32_t N, int32_t S, int32_t C, void* stream);

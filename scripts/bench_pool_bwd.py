@@ -1,0 +1,35 @@
+"""Times the stem's pooled BN backward (reduce + finalize + apply) at the bench geometry.
+usage: python scripts/bench_pool_bwd.py   (env VC_POOL_BWD_RH selects the apply form: 0 = gather)"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "video-classification_amd"))
+from vc3d import ops  # noqa: E402
+
+N, C, T, H, W = 64, 64, 16, 56, 56
+dev = "cuda"
+torch.manual_seed(0)
+y = (torch.randn(N, T, H, W, C, device=dev) * 1.3 + 0.2).to(torch.bfloat16)
+gamma = torch.ones(C, device=dev)
+beta = torch.zeros(C, device=dev)
+stats = ops.bn_stats(y, C)
+rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+prm = ops.bn_finalize(stats, y.numel() // C, gamma, beta, rm, rv, 0.1, 1e-5)
+pd = ops.pool_desc(N, C, T, H, W)
+pooled, idx = ops.maxpool3d_fwd(pd, y, prm)
+dp = torch.randn_like(pooled)
+dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+for use_pooled in (False, True):
+    for _ in range(3):
+        ops.bn_bwd_pooled(pd, y, dp, idx, prm, C, dg, db, pooled=pooled if use_pooled else None)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.bn_bwd_pooled(pd, y, dp, idx, prm, C, dg, db, pooled=pooled if use_pooled else None)
+    e1.record()
+    torch.cuda.synchronize()
+    print("RH=%s pooled=%d: %.1f us per reduce+finalize+apply" % (os.environ.get("VC_POOL_BWD_RH", "default"), use_pooled,
+                                                                 e0.elapsed_time(e1) * 1000 / 20))

@@ -332,6 +332,8 @@ def test_bn_bwd_through_pool_matches_unfused(shape):
     y = bf16_round(torch.randn(N, C, T, H, W, generator=g) * 1.3 + 0.2)
     gamma = 1 + 0.2 * torch.randn(C, generator=g)
     beta = 0.2 * torch.randn(C, generator=g)
+    gamma[3], beta[3] = 1e-3, 0.5  # |beta/gamma| large and gamma == 0: channels that keep the gather of y
+    gamma[5], beta[5] = 0.0, 0.3
     yd = to_nthwc_dev(y)
     stats = ops.bn_stats(yd, C)
     rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
@@ -347,6 +349,11 @@ def test_bn_bwd_through_pool_matches_unfused(shape):
     # fused
     dg1, db1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     dy1 = ops.bn_bwd_pooled(pd, yd, dpd, idx, prm, C, dg1, db1)
+    # the same with y at the arg-max solved from the pool's output instead of gathered
+    dg2, db2 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dy2 = ops.bn_bwd_pooled(pd, yd, dpd, idx, prm, C, dg2, db2, pooled=pooled)
+    assert rel_l2(dy2.float().cpu(), dy1.float().cpu()) <= 2e-3
+    assert rel_l2(dg2.cpu(), dg1.cpu()) <= 2e-3 and rel_l2(db2.cpu(), db1.cpu()) <= 1e-4
     # the unfused path rounds the pool-input gradient (a sum over up to 8 windows) to bf16, the fused one keeps it in fp32
     assert rel_l2(dy1.float().cpu(), dy0.float().cpu()) <= TOL_BF16
     assert rel_l2(dg1.cpu(), dg0.cpu()) <= 2e-3 and rel_l2(db1.cpu(), db0.cpu()) <= 2e-3

@@ -722,14 +722,14 @@ int vc_maxpool3d_bwd(const vc_pool3d_desc* d, const void* dout, const uint8_t* a
     return vc_ew_maxpool_bwd(dout, argmax, din, g, S(stream));
 }
 int vc_bn_bwd_reduce_pooled(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
-                            const float* params, float* sums, void* stream) {
+                            const void* pooled, const float* params, float* sums, void* stream) {
     VcPoolGeom g;
     int rc = pool_geom(d, g);
     if (rc) return rc;
     VC_REQUIRE(y && dpooled && argmax && params && sums, "bn_bwd_reduce_pooled: null pointer");
     VC_REQUIRE((long long)g.N * g.T * g.H < (1ll << 31), "bn_bwd_reduce_pooled: too many rows");
     VC_REQUIRE(pow2_channels(g.C), "bn: C=%d must be a power of two in [64, 2048]", g.C);
-    return vc_ew_bn_bwd_reduce_pooled(y, dpooled, argmax, params, sums, g, S(stream));
+    return vc_ew_bn_bwd_reduce_pooled(y, dpooled, argmax, pooled, params, sums, g, S(stream));
 }
 int vc_bn_bwd_apply_pooled(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
                            const float* params, const float* coef, void* dy, void* stream) {

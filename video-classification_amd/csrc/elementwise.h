@@ -43,7 +43,8 @@ int vc_ew_sgd_step(float* p, const float* g, float* mom, void* shadow, long n, f
                    int nesterov, hipStream_t s);
 int vc_ew_shadow(const float* p, void* shadow, long n, hipStream_t s);
 int vc_ew_pack_dgrad_batched(const void* shadow, void* wd, const int* table, int nconv, int tiles, hipStream_t s);
-int vc_ew_bn_bwd_reduce_pooled(const void* y, const void* dout, const uint8_t* idx, const float* params, float* sums,
+int vc_ew_bn_bwd_reduce_pooled(const void* y, const void* dout, const uint8_t* idx, const void* pooled, const float* params,
+                               float* sums,
                                const VcPoolGeom& g, hipStream_t s);
 int vc_ew_bn_bwd_apply_pooled(const void* y, const void* dout, const uint8_t* idx, const float* params, const float* coef,
                               void* dy, const VcPoolGeom& g, hipStream_t s);

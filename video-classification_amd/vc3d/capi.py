@@ -82,7 +82,7 @@ PROTOTYPES = {
     "vc_pool3d_out_dims": [_PD, _IP, _IP, _IP],
     "vc_maxpool3d_fwd": [_PD, _P, _P, _P, _P, _P],
     "vc_maxpool3d_bwd": [_PD, _P, _P, _P, _P],
-    "vc_bn_bwd_reduce_pooled": [_PD, _P, _P, _P, _P, _P, _P],
+    "vc_bn_bwd_reduce_pooled": [_PD, _P, _P, _P, _P, _P, _P, _P],
     "vc_bn_bwd_apply_pooled": [_PD, _P, _P, _P, _P, _P, _P, _P],
     "vc_gavgpool_fwd": [_P, _P, _I, _I, _I, _P],
     "vc_gavgpool_bwd": [_P, _P, _I, _I, _I, _P],

@@ -292,7 +292,7 @@ class R3DEngine:
         pd = ops.pool_desc(N, st.Co, T, H // 2, W // 2, pk, ps, pp)
         a0, idx = ops.maxpool3d_fwd(pd, y0, p0)
         self._t("conv1", clip=x, y=y0, prm=p0, pooled=a0)
-        saved = {"stem": (xs, y0, p0, pd, idx, (N, T, H, W)), "blocks": []} if save else None
+        saved = {"stem": (xs, y0, p0, pd, idx, a0, (N, T, H, W)), "blocks": []} if save else None
         if not save:
             del xs, y0, idx
         cur = a0
@@ -389,14 +389,14 @@ class R3DEngine:
                 del dy
             g = dz
         # stem: max pool -> BN+ReLU (mask recomputed) -> conv wgrad
-        xs, y0, p0, pd, idx, (N, T, H, W) = saved["stem"]
+        xs, y0, p0, pd, idx, a0, (N, T, H, W) = saved["stem"]
         st = self.stem
         if self.trace is not None:  # tests look at the materialised pool-input gradient as well
             din = ops.maxpool3d_bwd(pd, g, idx)
             self._t("conv1", dpooled=g, dz=din)
         if all(k <= 2 * s for k, s in zip(self.pool[0], self.pool[1])):
             dy0 = ops.bn_bwd_pooled(pd, y0, g, idx, p0, st.Co, self.gview(st.bn.weight), self.gview(st.bn.bias),
-                                    sums=sums_pool.take(st.Co))
+                                    sums=sums_pool.take(st.Co), pooled=a0)
         else:  # windows overlapping more than twice per axis: materialise the pool-input gradient
             dy0, _ = ops.bn_bwd(y0, ops.maxpool3d_bwd(pd, g, idx), p0, st.Co, self.gview(st.bn.weight),
                                 self.gview(st.bn.bias), mask=2, sums=sums_pool.take(st.Co))

@@ -338,14 +338,16 @@ def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=Fal
     return dy, g_out
 
 
-def bn_bwd_pooled(pd, y, dpooled, idx, params, C, gamma_grad, beta_grad, sums=None):
+def bn_bwd_pooled(pd, y, dpooled, idx, params, C, gamma_grad, beta_grad, sums=None, pooled=None):
     """BN+ReLU backward of the stem straight from the max-pool output gradient (no materialised
-    pool-input gradient).  Returns dy (gradient of the conv output)."""
+    pool-input gradient).  Returns dy (gradient of the conv output).  `pooled` = the pool's output
+    (maxpool3d_fwd with the same params): lets the reduction skip its element-wise gather of y."""
     To, Ho, Wo = pd.out_dims()
     n = pd.N * pd.T * pd.H * pd.W * pd.C
     _chk(y, BF16, n, "y")
     _chk(dpooled, BF16, pd.N * To * Ho * Wo * pd.C, "dpooled")
     _chk(idx, torch.uint8, pd.N * To * Ho * Wo * pd.C, "argmax")
+    _chk(pooled, BF16, pd.N * To * Ho * Wo * pd.C, "pooled")
     _chk(params, F32, 4 * C, "bn params")
     _chk(gamma_grad, F32, C, "dgamma")
     _chk(beta_grad, F32, C, "dbeta")
@@ -357,7 +359,7 @@ def bn_bwd_pooled(pd, y, dpooled, idx, params, C, gamma_grad, beta_grad, sums=No
     coef = torch.empty(2, C, dtype=F32, device=y.device)
     dy = torch.empty_like(y)
     s = cur_stream()
-    check(lib.vc_bn_bwd_reduce_pooled(pd, ptr(y), ptr(dpooled), ptr(idx), ptr(params), ptr(sums), s),
+    check(lib.vc_bn_bwd_reduce_pooled(pd, ptr(y), ptr(dpooled), ptr(idx), ptr(pooled), ptr(params), ptr(sums), s),
           "vc_bn_bwd_reduce_pooled")
     check(lib.vc_bn_bwd_finalize(ptr(sums), C, float(n // C), ptr(coef), ptr(gamma_grad), ptr(beta_grad), s),
           "vc_bn_bwd_finalize")
