@@ -35,7 +35,11 @@ struct IgemmCfg {
     static constexpr int NX = BM / 32;             // 1-KiB X pieces per wave per chunk
     static constexpr int NW = BCO / 32;            // 1-KiB W pieces per wave per chunk
     static constexpr int BUF_BYTES = (BCO + BM) * ROWB;
-    static constexpr int LDS_BYTES = 2 * BUF_BYTES;  // double buffered; the prologue's row table lives in buffer 1
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;  // double buffered
+    static constexpr int STAGE_BYTES = BM * (BCO * 2 + 16) + BM * 4;  // epilogue: staged output tile + row offsets
+    // a launch whose workgroups see a single K chunk (1x1x1 convs with 64 source channels) needs one buffer only:
+    // four workgroups per CU instead of two, i.e. twice the bytes in flight for what is a bandwidth-bound GEMM
+    static constexpr int LDS_BYTES_1 = BUF_BYTES > STAGE_BYTES ? BUF_BYTES : STAGE_BYTES;
     static_assert(WCO * WM == 4, "4 waves per workgroup");
     static_assert(BM * 12 <= BUF_BYTES, "row table must fit in one buffer");
 };
@@ -55,7 +59,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * BM;
     const int co0 = blockIdx.y * BCO;
     // output geometry: the launch's own, or that of this block's class
     int M = p.M, Ta = p.Ta, Ha = p.Ha, Wa = p.Wa, out_base = p.out_base, tap0 = 0, ntaps = p.ntaps;
@@ -69,73 +72,34 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
         dWa = p.cls[c].dWa, dHa = p.cls[c].dHa, dTa = p.cls[c].dTa;
         out_base = p.cls[c].out_base, tap0 = p.cls[c].tap0, ntaps = p.cls[c].ntaps;
         cps = (ntaps * (p.Cs >> 6) + zs - 1) / zs;
-        if (m0 >= M) return;  // the grid is sized for the largest class
     }
+    const int ntiles = (M + BM - 1) / BM;  // (the grid of a class launch is sized for the largest class)
 
-    // ---- per-row geometry, one row per thread, staged in buffer 1 (unused until the first prefetch)
-    int* sRowBase = (int*)(smem + Cfg::BUF_BYTES);
-    unsigned* sRowMask = (unsigned*)(sRowBase + BM);
-    int* sOutOff = (int*)(sRowMask + BM);
-    for (int r = tid; r < BM; r += 256) {
-        const int m = m0 + r;
-        int base = 0, ooff = -1;
-        unsigned mask = 0;
-        if (m < M) {
-            unsigned t1 = vc_div((unsigned)m, dWa);
-            int aw = m - (int)t1 * Wa;
-            unsigned t2 = vc_div(t1, dHa);
-            int ah = (int)t1 - (int)t2 * Ha;
-            unsigned n = vc_div(t2, dTa);
-            int at = (int)t2 - (int)n * Ta;
-            const int s_t = at * p.st, s_h = ah * p.sh, s_w = aw * p.sw;
-            base = ((((int)n * p.Ts + s_t) * p.Hs + s_h) * p.Ws + s_w) * p.Cs;
-            if (MODE == 0) {
-                for (int i = 0; i < ntaps; ++i) {
-                    const int tt = s_t + p.taps[tap0 + i].ot, hh = s_h + p.taps[tap0 + i].oh, ww = s_w + p.taps[tap0 + i].ow;
-                    const bool ok = (unsigned)tt < (unsigned)p.Ts && (unsigned)hh < (unsigned)p.Hs &&
-                                    (unsigned)ww < (unsigned)p.Ws;
-                    mask |= ok ? (1u << i) : 0u;
-                }
-            } else {
-                mask = 0xffffffffu;
-            }
-            ooff = out_base + (int)n * p.out_n + at * p.out_t + ah * p.out_h + aw * p.out_w;
-        }
-        sRowBase[r] = base;
-        sRowMask[r] = mask;
-        sOutOff[r] = ooff;
-    }
-    __syncthreads();
-
-    // ---- loader state: this lane fills LDS position (row = piece*32 + lrow, physical slot lane&7)
-    const int lrow = tid >> 3;                    // 0..31 = wave*8 + (lane>>3)
+    // ---- tile-independent lane roles
+    // loader: this lane fills LDS position (row = piece*32 + lrow, physical slot lane&7)
+    const int lrow = tid >> 3;                        // 0..31 = wave*8 + (lane>>3)
     const int lslot = (tid & 7) ^ ((lrow >> 1) & 7);  // logical (source) slot fetched by this lane
-    int rb[Cfg::NX];
-    unsigned rm[Cfg::NX];
-#pragma unroll
-    for (int i = 0; i < Cfg::NX; ++i) {
-        rb[i] = sRowBase[i * 32 + lrow] + (MODE == 0 ? lslot * 8 : 0);
-        rm[i] = sRowMask[i * 32 + lrow];
-    }
     int wb[Cfg::NW];
 #pragma unroll
     for (int j = 0; j < Cfg::NW; ++j) wb[j] = (co0 + j * 32 + lrow) * p.Kw + lslot * 8;
-
-    // ---- MFMA / epilogue lane roles
+    // MFMA / epilogue
     const int wco = wave % Cfg::WCO;
     const int wm = wave / Cfg::WCO;
     const int l15 = lane & 15;
     const int lg = lane >> 4;
     const int lswz = (lane >> 1) & 7;  // == ((row >> 1) & 7) for row = 16*x + l15
-    int ooff[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) ooff[b] = sOutOff[wm * 64 + b * 16 + l15];
-    __syncthreads();  // the row table has been consumed; buffer 1 may be overwritten
-
-    const int cpt = (MODE == 0) ? (p.Cs >> 6) : 1;               // chunks per tap
+    const int cobase = co0 + wco * 64 + lg * 4;
+    const int cpt = (MODE == 0) ? (p.Cs >> 6) : 1;  // chunks per tap
     const int nchunks = (MODE == 0) ? ntaps * cpt : (p.Kw >> 6);
     const gptr_t zero = (gptr_t)vc_zero_page;
+    int cbeg = 0, cend = nchunks;
+    if (p.splits > 1) {
+        cbeg = zsplit * cps;
+        cend = min(nchunks, cbeg + cps);
+    }
 
+    int rb[Cfg::NX];
+    unsigned rm[Cfg::NX];
     auto issue_chunk = [&](int ti, int c0, int chunk, int buf) {
         char* bW = smem + buf * Cfg::BUF_BYTES + wave * (8 * ROWB);
         char* bX = bW + BCO * ROWB;
@@ -161,122 +125,203 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
         }
     };
 
-    f32x4 acc[4][4];
+    // BatchNorm statistics: per-lane partial sums over this workgroup's tiles, reduced across lanes and added to
+    // the replicated accumulators once, after the tile loop (device-scope float atomics are the expensive part:
+    // one set per tile held a 64 -> 256 pointwise conv to half its bandwidth)
+    float st_s[4][4], st_q[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) st_s[a][j] = 0.f, st_q[a][j] = 0.f;
 
-    int cbeg = 0, cend = nchunks;
-    if (p.splits > 1) {
-        cbeg = zsplit * cps;
-        cend = min(nchunks, cbeg + cps);
-    }
-    int ti = 0, c0 = 0;
-    if (MODE == 0) {
-        ti = cbeg / cpt;
-        c0 = (cbeg - ti * cpt) * 64;
-    }
-    if (cbeg < cend) issue_chunk(ti, c0, cbeg, 0);
-
-    int buf = 0;
-    for (int c = cbeg; c < cend; ++c) {
-        // chunk c has landed for every wave (the barrier drains this wave's LDS-DMA first), and every
-        // wave is done reading the other buffer (it was read one iteration ago)
-        __syncthreads();
-        int nti = ti, nc0 = c0 + 64;
-        if (MODE == 0 && nc0 >= p.Cs) {
-            nc0 = 0;
-            nti = ti + 1;
+    // A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the host caps gridDim.x for single-geometry
+    // launches so that all workgroups are resident and own the same number of tiles).
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * BM;
+        // ---- per-row geometry, one row per thread, staged in buffer 0 (consumed before the first chunk is issued)
+        int* sRowBase = (int*)smem;
+        unsigned* sRowMask = (unsigned*)(sRowBase + BM);
+        int* sOutOff = (int*)(sRowMask + BM);
+        int my_ooff = -1;  // out offset of row tid (BM <= 256), put back into LDS for the staged store
+        for (int r = tid; r < BM; r += 256) {
+            const int m = m0 + r;
+            int base = 0, ooff = -1;
+            unsigned mask = 0;
+            if (m < M) {
+                unsigned t1 = vc_div((unsigned)m, dWa);
+                int aw = m - (int)t1 * Wa;
+                unsigned t2 = vc_div(t1, dHa);
+                int ah = (int)t1 - (int)t2 * Ha;
+                unsigned n = vc_div(t2, dTa);
+                int at = (int)t2 - (int)n * Ta;
+                const int s_t = at * p.st, s_h = ah * p.sh, s_w = aw * p.sw;
+                base = ((((int)n * p.Ts + s_t) * p.Hs + s_h) * p.Ws + s_w) * p.Cs;
+                if (MODE == 0) {
+                    for (int i = 0; i < ntaps; ++i) {
+                        const int tt = s_t + p.taps[tap0 + i].ot, hh = s_h + p.taps[tap0 + i].oh,
+                                  ww = s_w + p.taps[tap0 + i].ow;
+                        const bool ok = (unsigned)tt < (unsigned)p.Ts && (unsigned)hh < (unsigned)p.Hs &&
+                                        (unsigned)ww < (unsigned)p.Ws;
+                        mask |= ok ? (1u << i) : 0u;
+                    }
+                } else {
+                    mask = 0xffffffffu;
+                }
+                ooff = out_base + (int)n * p.out_n + at * p.out_t + ah * p.out_h + aw * p.out_w;
+            }
+            sRowBase[r] = base;
+            sRowMask[r] = mask;
+            sOutOff[r] = ooff;
+            my_ooff = ooff;
         }
-        if (c + 1 < cend) issue_chunk(nti, nc0, c + 1, buf ^ 1);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < Cfg::NX; ++i) {
+            rb[i] = sRowBase[i * 32 + lrow] + (MODE == 0 ? lslot * 8 : 0);
+            rm[i] = sRowMask[i * 32 + lrow];
+        }
+        int ooff[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ooff[b] = sOutOff[wm * 64 + b * 16 + l15];
+        __syncthreads();  // the row table has been consumed; buffer 0 may be overwritten
 
-        const char* sW = smem + buf * Cfg::BUF_BYTES;
-        const char* sX = sW + BCO * ROWB;
+        f32x4 acc[4][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
-            const int slot = ((ks << 2) + lg) ^ lswz;
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-                fa[a] = *(const bf16x8*)(sW + (wco * 64 + a * 16 + l15) * ROWB + (slot << 4));
+            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        int ti = 0, c0 = 0;
+        if (MODE == 0) {
+            ti = cbeg / cpt;
+            c0 = (cbeg - ti * cpt) * 64;
+        }
+        if (cbeg < cend) issue_chunk(ti, c0, cbeg, 0);
+
+        int buf = 0;
+        for (int c = cbeg; c < cend; ++c) {
+            // chunk c has landed for every wave (the barrier drains this wave's LDS-DMA first), and every
+            // wave is done reading the other buffer (it was read one iteration ago)
+            __syncthreads();
+            int nti = ti, nc0 = c0 + 64;
+            if (MODE == 0 && nc0 >= p.Cs) {
+                nc0 = 0;
+                nti = ti + 1;
+            }
+            if (c + 1 < cend) issue_chunk(nti, nc0, c + 1, buf ^ 1);
+
+            const char* sW = smem + buf * Cfg::BUF_BYTES;
+            const char* sX = sW + BCO * ROWB;
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                fb[b] = *(const bf16x8*)(sX + (wm * 64 + b * 16 + l15) * ROWB + (slot << 4));
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[4], fb[4];
+                const int slot = ((ks << 2) + lg) ^ lswz;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 4; ++a)
+                    fa[a] = *(const bf16x8*)(sW + (wco * 64 + a * 16 + l15) * ROWB + (slot << 4));
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                    fb[b] = *(const bf16x8*)(sX + (wm * 64 + b * 16 + l15) * ROWB + (slot << 4));
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+            ti = nti;
+            c0 = nc0;
+            buf ^= 1;
         }
-        ti = nti;
-        c0 = nc0;
-        buf ^= 1;
-    }
 
-    // ---- epilogue ----
-    // acc[a][b][j] = D[co = co0 + wco*64 + a*16 + lg*4 + j][m = m0 + wm*64 + b*16 + l15]
-    const int cobase = co0 + wco * 64 + lg * 4;
+        // ---- epilogue ----
+        // acc[a][b][j] = D[co = co0 + wco*64 + a*16 + lg*4 + j][m = m0 + wm*64 + b*16 + l15]
+        if (p.partial != nullptr) {
+            float* slab = p.partial + (size_t)zsplit * p.partial_stride;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (ooff[b] < 0) continue;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) *(f32x4*)(slab + (size_t)ooff[b] + cobase + a * 16) = acc[a][b];
+            }
+            __syncthreads();  // the operand tiles have been read before the next tile's row table lands on them
+            continue;
+        }
 
-    if (p.partial != nullptr) {
-        float* slab = p.partial + (size_t)zsplit * p.partial_stride;
+        if (p.stats != nullptr) {  // rows beyond M hold exact zeros
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const float v = acc[a][b][j];
+                        st_s[a][j] += v;
+                        st_q[a][j] += v * v;
+                    }
+        }
+
+        // ---- store through LDS: the accumulator layout gives a lane 4 channels (8 bytes) of one position; staged,
+        // every global access is a whole 16-byte piece of a channels-last row, 16 (or 8) lanes per row.  With
+        // `accumulate` the old output takes the same way in, and the add and the single rounding happen on the fp32
+        // accumulators.
+        constexpr int OPITCH = BCO * 2 + 16;  // bytes per staged row
+        constexpr int PPR = BCO / 8;          // 16-byte pieces per row
+        static_assert(Cfg::STAGE_BYTES <= Cfg::LDS_BYTES, "staging tile and row table must fit");
+        __syncthreads();  // every wave has finished reading the operand tiles
+        int* sOut = (int*)(smem + BM * OPITCH);
+        if (tid < BM) sOut[tid] = my_ooff;
+        __syncthreads();
+        if (p.accumulate) {
+            for (int i = tid; i < BM * PPR; i += 256) {
+                const int r = i / PPR, c8 = i - r * PPR;
+                const int oo = sOut[r];
+                if (oo >= 0) *(bf16x8*)(smem + r * OPITCH + c8 * 16) = *(const bf16x8*)(p.out + (size_t)oo + co0 + c8 * 8);
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            if (ooff[b] < 0) continue;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) *(f32x4*)(slab + (size_t)ooff[b] + cobase + a * 16) = acc[a][b];
+            for (int a = 0; a < 4; ++a) {
+                bf16x4* q = (bf16x4*)(smem + (wm * 64 + b * 16 + l15) * OPITCH + (wco * 64 + a * 16 + lg * 4) * 2);
+                f32x4 v = acc[a][b];
+                if (p.accumulate) {
+                    const bf16x4 old = *q;
+                    v[0] += bf2f(old[0]);
+                    v[1] += bf2f(old[1]);
+                    v[2] += bf2f(old[2]);
+                    v[3] += bf2f(old[3]);
+                }
+                bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *q = o;
+            }
         }
-        return;
+        __syncthreads();
+        for (int i = tid; i < BM * PPR; i += 256) {
+            const int r = i / PPR, c8 = i - r * PPR;
+            const int oo = sOut[r];
+            if (oo >= 0) *(bf16x8*)(p.out + (size_t)oo + co0 + c8 * 8) = *(const bf16x8*)(smem + r * OPITCH + c8 * 16);
+        }
+        __syncthreads();  // the staged tile has been read out before the next tile's row table is written
     }
 
-    if (p.stats != nullptr) {
+    if (p.stats != nullptr && p.partial == nullptr) {
         float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            float s[4], q[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float ss = 0.f, qq = 0.f;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const float v = acc[a][b][j];
-                    ss += v;
-                    qq += v * v;
-                }
+                float ss = st_s[a][j], qq = st_q[a][j];
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) {
                     ss += __shfl_xor(ss, o);
                     qq += __shfl_xor(qq, o);
                 }
-                s[j] = ss;
-                q[j] = qq;
-            }
-            if (l15 == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    atomicAdd(srep + cobase + a * 16 + j, s[j]);
-                    atomicAdd(srep + p.Cn + cobase + a * 16 + j, q[j]);
+                if (l15 == 0) {
+                    atomicAdd(srep + cobase + a * 16 + j, ss);
+                    atomicAdd(srep + p.Cn + cobase + a * 16 + j, qq);
                 }
             }
-        }
-    }
-
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        if (ooff[b] < 0) continue;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            bf16* dst = p.out + (size_t)ooff[b] + cobase + a * 16;
-            f32x4 v = acc[a][b];
-            if (p.accumulate) {
-                const bf16x4 old = *(const bf16x4*)dst;
-                v[0] += bf2f(old[0]);
-                v[1] += bf2f(old[1]);
-                v[2] += bf2f(old[2]);
-                v[3] += bf2f(old[3]);
-            }
-            bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-            *(bf16x4*)dst = o;
         }
     }
 }
@@ -285,8 +330,18 @@ template <int BCO, int BM, int MODE>
 int launch_igemm(const VcIgemmParams& p, hipStream_t stream) {
     using Cfg = IgemmCfg<BCO, BM>;
     dim3 grid((p.M + BM - 1) / BM, p.Cn / BCO, (p.splits > 1 ? p.splits : 1) * (p.ncls > 1 ? p.ncls : 1));
+    const bool one_chunk = MODE == 0 && p.ncls <= 1 && p.ntaps * (p.Cs >> 6) == 1;
+    if (p.ncls <= 1 && p.splits <= 1) {
+        // persistent over tiles: all workgroups resident (2 per CU, 4 with a single buffer), same tile count each
+        const long resident = 256l * (one_chunk ? 4 : 2);
+        const long cap_x = resident / grid.y > 0 ? resident / grid.y : 1;
+        if ((long)grid.x > cap_x) {
+            const long per = ((long)grid.x + cap_x - 1) / cap_x;
+            grid.x = (unsigned)(((long)grid.x + per - 1) / per);
+        }
+    }
     (void)hipGetLastError();  // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((igemm_kernel<BCO, BM, MODE>), grid, dim3(256), Cfg::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<BCO, BM, MODE>), grid, dim3(256), one_chunk ? Cfg::LDS_BYTES_1 : Cfg::LDS_BYTES, stream, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         vc_set_error("igemm launch failed: %s", hipGetErrorString(e));
