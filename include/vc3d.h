@@ -61,6 +61,22 @@ size_t vc_conv3d_workspace_bytes(const vc_conv3d_desc* d, int32_t op);
 int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y,
                   float* bn_stats /* nullable: fused sum / sum-of-squares of y */, void* workspace,
                   size_t ws_bytes, void* stream);
+/* BatchNorm finalize folded into the launch that produces the sums (reference backbone.py:39-42,114: the
+ * BatchNorm that follows every conv).  The workgroup that finishes last does vc_bn_finalize's work -- same
+ * arithmetic, one launch less per layer.  `ticket`: one uint32 in device memory, zero before its first use; the
+ * launch leaves it zero, so a zero-initialised word per layer is reused step after step.  Launches that share a
+ * ticket word must not overlap.  `count` = elements per channel (N*T*H*W of y). */
+typedef struct vc_bn_fin {
+    uint32_t* ticket;
+    const float* gamma;
+    const float* beta;
+    float* running_mean; /* nullable, with running_var */
+    float* running_var;
+    float* params;       /* out [4][C]: mean, invstd, scale, shift (as vc_bn_finalize) */
+    float count, momentum, eps;
+} vc_bn_fin;
+int vc_conv3d_fwd_bn(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats,
+                     const vc_bn_fin* fin, void* workspace, size_t ws_bytes, void* stream);
 int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx,
                     int accumulate /* dx += instead of dx = */, void* workspace, size_t ws_bytes,
                     void* stream);
@@ -95,6 +111,8 @@ int vc_stem_pack_input(const void* x, int32_t x_is_bf16, void* xs, int32_t N, in
 int vc_stem_pack_weight(const float* w_master /* [Co][7][7][7][3] */, void* ws, int32_t Co, void* stream);
 int vc_stem_fwd(const void* xs, const void* ws, void* y /* [N][T][H/2][W/2][Co] */, float* bn_stats,
                 int32_t N, int32_t T, int32_t H, int32_t W, int32_t Co, void* stream);
+int vc_stem_fwd_bn(const void* xs, const void* ws, void* y, float* bn_stats, const vc_bn_fin* fin, int32_t N,
+                   int32_t T, int32_t H, int32_t W, int32_t Co, void* stream);
 /* `workspace` (device, caller-owned, nullable): per-workgroup fp32 partials of the image-resident stem weight
  * gradient; vc_stem_wgrad_workspace_bytes reports the need (0: the generic kernel runs, as it does when the
  * workspace is absent or too small). */
@@ -121,6 +139,11 @@ int vc_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float
                      int64_t rows, int32_t C, int32_t mask, void* stream);
 int vc_bn_bwd_finalize(const float* sums, int32_t C, float count, float* coef /* [2][C] */,
                        float* dgamma /* += nullable */, float* dbeta /* += nullable */, void* stream);
+/* vc_bn_bwd_reduce with vc_bn_bwd_finalize folded in (the last workgroup does it; `ticket` as in vc_bn_fin;
+ * count = rows). */
+int vc_bn_bwd_reduce_fin(const void* y, const void* dz, const void* aux, const float* params, float* sums,
+                         int64_t rows, int32_t C, int32_t mask, uint32_t* ticket, float* coef /* [2][C] */,
+                         float* dgamma /* += nullable */, float* dbeta /* += nullable */, void* stream);
 int vc_bn_bwd_apply(const void* y, const void* dz, const void* aux, const float* params,
                     const float* coef, void* dy, void* g_out /* nullable: masked dz */, int64_t elems,
                     int32_t C, int32_t mask, void* stream);
@@ -142,6 +165,9 @@ int vc_maxpool3d_bwd(const vc_pool3d_desc* d, const void* dout, const uint8_t* a
  * instead of gathering y element by element (channels with |beta| > 16 |gamma| keep the gather). */
 int vc_bn_bwd_reduce_pooled(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
                             const void* pooled, const float* params, float* sums, void* stream);
+int vc_bn_bwd_reduce_pooled_fin(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
+                                const void* pooled, const float* params, float* sums, uint32_t* ticket,
+                                float* coef, float* dgamma, float* dbeta, void* stream);
 int vc_bn_bwd_apply_pooled(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
                            const float* params, const float* coef, void* dy, void* stream);
 int vc_gavgpool_fwd(const void* in, float* out, int32_t N, int32_t S, int32_t C, void* stream);

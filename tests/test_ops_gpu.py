@@ -105,6 +105,8 @@ def _conv_case(case):
     ref_q = (y_ref.detach() ** 2).sum(dim=(0, 2, 3, 4))
     assert float((st[0] - ref_s).abs().max()) <= 1e-3 * float(ref_q.max().sqrt() * (y_ref[0, 0].numel() * N) ** 0.5)
     assert rel_l2(st[1], ref_q) <= TOL_F32
+    _check_fused_finalize(lambda st2, fin: ops.conv3d_fwd(d, xd, wf, stats=st2, fin=fin), y, Co,
+                          N * y_ref.shape[2] * y_ref.shape[3] * y_ref.shape[4])
 
     dyd = to_nthwc_dev(dy)
     dx = ops.conv3d_dgrad(d, dyd, wd)
@@ -121,6 +123,29 @@ def _conv_case(case):
     torch.cuda.synchronize()
     dw_h = dw.cpu().permute(0, 4, 1, 2, 3)
     assert rel_l2(dw_h, w.grad) <= TOL_F32
+
+
+def _check_fused_finalize(run, y_plain, C, count):
+    """BatchNorm finalize done by the producing launch's last workgroup == the separate vc_bn_finalize launch on the
+    same sums (the sums themselves differ by the arrival order of float atomics only), twice in a row on ONE ticket
+    word (the launch must leave it zero), running statistics included."""
+    from vc3d import ops
+    g = torch.Generator().manual_seed(C)
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    beta = (torch.randn(C, generator=g) * 0.1).cuda()
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    rm0, rv0 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    for _ in range(2):
+        st2 = ops.new_stats(C, "cuda")
+        fin, prm = ops.bn_fin(ticket, count, gamma, beta, rm, rv, 0.1, 1e-5)
+        y2 = run(st2, fin)
+        prm0 = ops.bn_finalize(st2, count, gamma, beta, rm0, rv0, 0.1, 1e-5)
+        torch.cuda.synchronize()
+        assert int(ticket.item()) == 0
+        assert torch.equal(y2, y_plain)
+        assert torch.allclose(prm, prm0, rtol=1e-6, atol=1e-7), float((prm - prm0).abs().max())
+        assert torch.allclose(rm, rm0, rtol=1e-6, atol=1e-7) and torch.allclose(rv, rv0, rtol=1e-6, atol=1e-7)
 
 
 # the last shapes: ragged last row group + odd T (image-resident kernels: several units, frame pairs with an idle
@@ -148,6 +173,8 @@ def test_stem_fwd_wgrad(shape):
     assert rel_l2(from_nthwc(y), y_ref.detach()) <= TOL_BF16
     st = stats.sum(0).cpu()
     assert rel_l2(st[1], (y_ref.detach() ** 2).sum(dim=(0, 2, 3, 4))) <= TOL_F32
+    _check_fused_finalize(lambda st2, fin: ops.stem_fwd(xs, ws, N, T, H, W, Co, stats=st2, fin=fin), y, Co,
+                          N * T * (H // 2) * (W // 2))
 
     dwm = torch.zeros(Co, 7, 7, 7, 3, dtype=torch.float32, device="cuda")
     ops.stem_wgrad(xs, to_nthwc_dev(dy), N, T, H, W, Co, dwm)
@@ -208,6 +235,15 @@ def test_batchnorm_fwd_bwd(C, shape, mode):
     assert rel_l2(dbeta.cpu(), bn.bias.grad) <= 5e-3
     if mode == "res_relu":
         assert rel_l2(from_nthwc(gm), res.grad) <= TOL_BF16
+    # finalize folded into the reduction (its last workgroup): same result, ticket word left zero, twice in a row
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        dg3, db3 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dy3, _ = ops.bn_bwd(yd, to_nthwc_dev(dz), params, C, dg3, db3, mask=mask, aux=z if mask else None, ticket=ticket)
+        torch.cuda.synchronize()
+        assert int(ticket.item()) == 0
+        assert rel_l2(dy3.float(), dy.float()) <= 1e-3
+        assert torch.allclose(dg3, dgamma, rtol=1e-4, atol=1e-5) and torch.allclose(db3, dbeta, rtol=1e-4, atol=1e-5)
     if mode == "relu":
         # recomputed mask (y*scale+shift > 0) must agree with the saved-output mask
         dg2 = torch.zeros(C, device="cuda")
@@ -354,6 +390,14 @@ def test_bn_bwd_through_pool_matches_unfused(shape):
     dy2 = ops.bn_bwd_pooled(pd, yd, dpd, idx, prm, C, dg2, db2, pooled=pooled)
     assert rel_l2(dy2.float().cpu(), dy1.float().cpu()) <= 2e-3
     assert rel_l2(dg2.cpu(), dg1.cpu()) <= 2e-3 and rel_l2(db2.cpu(), db1.cpu()) <= 1e-4
+    # and with the finalize folded into the reduction
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dg3, db3 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dy3 = ops.bn_bwd_pooled(pd, yd, dpd, idx, prm, C, dg3, db3, pooled=pooled, ticket=ticket)
+    torch.cuda.synchronize()
+    assert int(ticket.item()) == 0
+    assert rel_l2(dy3.float().cpu(), dy2.float().cpu()) <= 1e-3
+    assert torch.allclose(dg3, dg2, rtol=1e-4, atol=1e-5) and torch.allclose(db3, db2, rtol=1e-4, atol=1e-5)
     # the unfused path rounds the pool-input gradient (a sum over up to 8 windows) to bf16, the fused one keeps it in fp32
     assert rel_l2(dy1.float().cpu(), dy0.float().cpu()) <= TOL_BF16
     assert rel_l2(dg1.cpu(), dg0.cpu()) <= 2e-3 and rel_l2(db1.cpu(), db0.cpu()) <= 2e-3

@@ -58,6 +58,7 @@ static int conv_check(const vc_conv3d_desc* d, int& To, int& Ho, int& Wo) {
 }
 
 static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const void* w, void* out, float* stats,
+                    const VcBnFin* fin,
                     int accumulate, void* workspace, size_t ws_bytes, void* stream);
 
 extern "C" {
@@ -217,13 +218,13 @@ size_t vc_conv3d_workspace_bytes(const vc_conv3d_desc* d, int32_t op) {
     return 0;
 }
 
-int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, void* workspace,
-                  size_t ws_bytes, void* stream) {
+static int conv3d_fwd_impl(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats,
+                           const VcBnFin* fin, void* workspace, size_t ws_bytes, void* stream) {
     int To, Ho, Wo;
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(x && w && y, "conv3d_fwd: null pointer");
-    if (halo_ok(d)) return halo_run(d, false, x, w, y, bn_stats, 0, workspace, ws_bytes, stream);
+    if (halo_ok(d)) return halo_run(d, false, x, w, y, bn_stats, fin, 0, workspace, ws_bytes, stream);
     VcIgemmParams p;
     memset(&p, 0, sizeof(p));
     p.src = (const bf16*)x;
@@ -260,14 +261,39 @@ int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y
         p.stats = nullptr;
         rc = vc_launch_igemm(p, 0, S(stream));
         if (rc) return rc;
-        return vc_ew_splitk_finalize(p.partial, splits, p.partial_stride, y, 0, bn_stats, p.M, d->Co, S(stream));
+        return vc_ew_splitk_finalize(p.partial, splits, p.partial_stride, y, 0, bn_stats, p.M, d->Co, fin, S(stream));
     }
+    if (fin != nullptr && bn_stats != nullptr) p.fin = *fin;
     return vc_launch_igemm(p, 0, S(stream));
+}
+
+// public vc_bn_fin -> internal descriptor (validated)
+static int make_fin(const vc_bn_fin* f, const float* stats, VcBnFin& o) {
+    VC_REQUIRE(f && stats, "fused BatchNorm finalize needs bn_stats and a vc_bn_fin");
+    VC_REQUIRE(f->ticket && f->gamma && f->beta && f->params && f->count > 0.f, "vc_bn_fin: bad arguments");
+    VC_REQUIRE((f->running_mean == nullptr) == (f->running_var == nullptr), "vc_bn_fin: running statistics come in pairs");
+    o.ticket = f->ticket, o.gamma = f->gamma, o.beta = f->beta;
+    o.running_mean = f->running_mean, o.running_var = f->running_var, o.params = f->params;
+    o.count = f->count, o.momentum = f->momentum, o.eps = f->eps;
+    return 0;
+}
+
+int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, void* workspace,
+                  size_t ws_bytes, void* stream) {
+    return conv3d_fwd_impl(d, x, w, y, bn_stats, nullptr, workspace, ws_bytes, stream);
+}
+int vc_conv3d_fwd_bn(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, const vc_bn_fin* fin,
+                     void* workspace, size_t ws_bytes, void* stream) {
+    VcBnFin f;
+    int rc = make_fin(fin, bn_stats, f);
+    if (rc) return rc;
+    return conv3d_fwd_impl(d, x, w, y, bn_stats, &f, workspace, ws_bytes, stream);
 }
 
 }  // extern "C"
 
 static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const void* w, void* out, float* stats,
+                    const VcBnFin* fin,
                     int accumulate, void* workspace, size_t ws_bytes, void* stream) {
     VcHaloPlan plan;
     if (halo_plan(d, dgrad, &plan)) {
@@ -291,9 +317,14 @@ static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const 
         int rc = vc_launch_halo(p, plan, S(stream));
         if (rc) return rc;
         return vc_ew_splitk_finalize(p.partial, plan.splits, p.partial_stride, out, accumulate, stats,
-                                     (long)(out_e / p.Cn), p.Cn, S(stream));
+                                     (long)(out_e / p.Cn), p.Cn, stats ? fin : nullptr, S(stream));
     }
-    return vc_launch_halo(p, plan, S(stream));
+    // The halo kernel runs several rounds of one workgroup per CU: a ticket round trip at the end of every workgroup
+    // costs more there than the separate finalize launch (measured), so the finalize stays a launch of its own.
+    int rc = vc_launch_halo(p, plan, S(stream));
+    if (rc || fin == nullptr || stats == nullptr) return rc;
+    return vc_ew_bn_finalize(stats, p.Cn, fin->count, fin->gamma, fin->beta, fin->running_mean, fin->running_var,
+                             fin->momentum, fin->eps, fin->params, S(stream));
 }
 
 extern "C" {
@@ -307,7 +338,7 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(dy && w_dgrad && dx, "conv3d_dgrad: null pointer");
-    if (halo_ok(d)) return halo_run(d, true, dy, w_dgrad, dx, nullptr, accumulate, workspace, ws_bytes, stream);
+    if (halo_ok(d)) return halo_run(d, true, dy, w_dgrad, dx, nullptr, nullptr, accumulate, workspace, ws_bytes, stream);
     const int ntaps_all = d->kt * d->kh * d->kw;
     const size_t dx_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
     int splits = dgrad_splits(d);
@@ -416,7 +447,7 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
     }
     if (splits > 1)
         return vc_ew_splitk_finalize((const float*)workspace, splits, (long long)dx_e, dx, accumulate, nullptr,
-                                     (long)(dx_e / d->Ci), d->Ci, S(stream));
+                                     (long)(dx_e / d->Ci), d->Ci, nullptr, S(stream));
     return 0;
 }
 
@@ -555,8 +586,8 @@ static void stem_geometry(int N, int T, int H, int W, int& M, int& Ho, int& Wo, 
     M = N * T * Ho * Wo;
 }
 
-int vc_stem_fwd(const void* xs, const void* ws, void* y, float* bn_stats, int32_t N, int32_t T, int32_t H, int32_t W,
-                int32_t Co, void* stream) {
+static int stem_fwd_impl(const void* xs, const void* ws, void* y, float* bn_stats, const VcBnFin* fin, int32_t N,
+                         int32_t T, int32_t H, int32_t W, int32_t Co, void* stream) {
     int rc = stem_check(N, T, H, W, Co);
     if (rc) return rc;
     VC_REQUIRE(xs && ws && y, "stem_fwd: null pointer");
@@ -568,6 +599,7 @@ int vc_stem_fwd(const void* xs, const void* ws, void* y, float* bn_stats, int32_
         sp.ws = (const bf16*)ws;
         sp.y = (bf16*)y;
         sp.stats = bn_stats;
+        if (fin != nullptr && bn_stats != nullptr) sp.fin = *fin;
         return vc_launch_stem_fwd(sp, S(stream));
     }
     VcIgemmParams p;
@@ -585,7 +617,19 @@ int vc_stem_fwd(const void* xs, const void* ws, void* y, float* bn_stats, int32_
     p.Kw = 1344;
     p.Cn = Co;
     p.out_w = Co, p.out_h = Wo * Co, p.out_t = Ho * Wo * Co, p.out_n = T * Ho * Wo * Co, p.out_base = 0;
+    if (fin != nullptr && bn_stats != nullptr) p.fin = *fin;
     return vc_launch_igemm(p, 1, S(stream));
+}
+int vc_stem_fwd(const void* xs, const void* ws, void* y, float* bn_stats, int32_t N, int32_t T, int32_t H, int32_t W,
+                int32_t Co, void* stream) {
+    return stem_fwd_impl(xs, ws, y, bn_stats, nullptr, N, T, H, W, Co, stream);
+}
+int vc_stem_fwd_bn(const void* xs, const void* ws, void* y, float* bn_stats, const vc_bn_fin* fin, int32_t N, int32_t T,
+                   int32_t H, int32_t W, int32_t Co, void* stream) {
+    VcBnFin f;
+    int rc = make_fin(fin, bn_stats, f);
+    if (rc) return rc;
+    return stem_fwd_impl(xs, ws, y, bn_stats, &f, N, T, H, W, Co, stream);
 }
 
 size_t vc_stem_wgrad_workspace_bytes(int32_t N, int32_t T, int32_t H, int32_t W, int32_t Co) {
@@ -638,7 +682,7 @@ int vc_stem_unpack_wgrad(const float* dws, float* dw_master, int32_t Co, void* s
 int vc_bn_stats(const void* y, float* sums, int64_t rows, int32_t C, void* stream) {
     VC_REQUIRE(y && sums && rows > 0, "bn_stats: bad arguments");
     VC_REQUIRE(pow2_channels(C), "bn: C=%d must be a power of two in [64, 2048]", C);
-    return vc_ew_bn_stats(y, sums, rows, C, S(stream));
+    return vc_ew_bn_stats(y, sums, rows, C, nullptr, S(stream));
 }
 int vc_bn_finalize(const float* stats, int32_t C, float count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, float* params, void* stream) {
@@ -662,7 +706,17 @@ int vc_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float
     VC_REQUIRE(y && dz && params && sums && rows > 0, "bn_bwd_reduce: bad arguments");
     VC_REQUIRE(pow2_channels(C), "bn: C=%d must be a power of two in [64, 2048]", C);
     VC_REQUIRE(mask >= 0 && mask <= 2 && (mask != 1 || aux), "bn_bwd_reduce: bad mask mode");
-    return vc_ew_bn_bwd_reduce(y, dz, aux, params, sums, rows, C, mask, S(stream));
+    return vc_ew_bn_bwd_reduce(y, dz, aux, params, sums, rows, C, mask, nullptr, S(stream));
+}
+int vc_bn_bwd_reduce_fin(const void* y, const void* dz, const void* aux, const float* params, float* sums, int64_t rows,
+                         int32_t C, int32_t mask, uint32_t* ticket, float* coef, float* dgamma, float* dbeta,
+                         void* stream) {
+    VC_REQUIRE(y && dz && params && sums && rows > 0, "bn_bwd_reduce_fin: bad arguments");
+    VC_REQUIRE(pow2_channels(C), "bn: C=%d must be a power of two in [64, 2048]", C);
+    VC_REQUIRE(mask >= 0 && mask <= 2 && (mask != 1 || aux), "bn_bwd_reduce_fin: bad mask mode");
+    VC_REQUIRE(ticket && coef, "bn_bwd_reduce_fin: ticket and coef are required");
+    const VcBnBwdFin f = {ticket, coef, dgamma, dbeta, (float)rows};
+    return vc_ew_bn_bwd_reduce(y, dz, aux, params, sums, rows, C, mask, &f, S(stream));
 }
 int vc_bn_bwd_finalize(const float* sums, int32_t C, float count, float* coef, float* dgamma, float* dbeta,
                        void* stream) {
@@ -729,7 +783,19 @@ int vc_bn_bwd_reduce_pooled(const vc_pool3d_desc* d, const void* y, const void* 
     VC_REQUIRE(y && dpooled && argmax && params && sums, "bn_bwd_reduce_pooled: null pointer");
     VC_REQUIRE((long long)g.N * g.T * g.H < (1ll << 31), "bn_bwd_reduce_pooled: too many rows");
     VC_REQUIRE(pow2_channels(g.C), "bn: C=%d must be a power of two in [64, 2048]", g.C);
-    return vc_ew_bn_bwd_reduce_pooled(y, dpooled, argmax, pooled, params, sums, g, S(stream));
+    return vc_ew_bn_bwd_reduce_pooled(y, dpooled, argmax, pooled, params, sums, g, nullptr, S(stream));
+}
+int vc_bn_bwd_reduce_pooled_fin(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
+                                const void* pooled, const float* params, float* sums, uint32_t* ticket, float* coef,
+                                float* dgamma, float* dbeta, void* stream) {
+    VcPoolGeom g;
+    int rc = pool_geom(d, g);
+    if (rc) return rc;
+    VC_REQUIRE(y && dpooled && argmax && params && sums && ticket && coef, "bn_bwd_reduce_pooled_fin: null pointer");
+    VC_REQUIRE((long long)g.N * g.T * g.H < (1ll << 31), "bn_bwd_reduce_pooled_fin: too many rows");
+    VC_REQUIRE(pow2_channels(g.C), "bn: C=%d must be a power of two in [64, 2048]", g.C);
+    const VcBnBwdFin f = {ticket, coef, dgamma, dbeta, (float)((long long)g.N * g.T * g.H * g.W)};
+    return vc_ew_bn_bwd_reduce_pooled(y, dpooled, argmax, pooled, params, sums, g, &f, S(stream));
 }
 int vc_bn_bwd_apply_pooled(const vc_pool3d_desc* d, const void* y, const void* dpooled, const uint8_t* argmax,
                            const float* params, const float* coef, void* dy, void* stream) {

@@ -1,6 +1,7 @@
 // Launch wrappers of elementwise.hip (internal; the C ABI in capi.hip validates and forwards).
 #pragma once
 #include "common.h"
+#include "bn_fin.h"
 
 struct VcPoolGeom {
     int N, C, T, H, W;
@@ -14,15 +15,15 @@ int vc_ew_bn_eval_params(int C, const float* gamma, const float* beta, const flo
                          float* params, hipStream_t s);
 int vc_ew_bn_apply(const void* y, const float* params, const void* res, void* out, long n, int C, int relu,
                    hipStream_t s);
-int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, hipStream_t s);
+int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, const VcBnFin* fin, hipStream_t s);
 int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums, long rows,
-                        int C, int mask, hipStream_t s);
+                        int C, int mask, const VcBnBwdFin* fin, hipStream_t s);
 int vc_ew_bn_bwd_finalize(const float* sums, int C, float count, float* coef, float* dgamma, float* dbeta,
                           hipStream_t s);
 int vc_ew_bn_bwd_apply(const void* y, const void* dz, const void* aux, const float* params, const float* coef, void* dy,
                        void* gout, long n, int C, int mask, hipStream_t s);
 int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void* out, int accumulate, float* stats,
-                          long rows, int C, hipStream_t s);
+                          long rows, int C, const VcBnFin* fin, hipStream_t s);
 int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, hipStream_t s);
 int vc_ew_add(const void* a, const void* b, void* out, long n, hipStream_t s);
 int vc_ew_maxpool_fwd(const void* y, const float* params, void* out, uint8_t* idx, const VcPoolGeom& g, hipStream_t s);
@@ -44,7 +45,6 @@ int vc_ew_sgd_step(float* p, const float* g, float* mom, void* shadow, long n, f
 int vc_ew_shadow(const float* p, void* shadow, long n, hipStream_t s);
 int vc_ew_pack_dgrad_batched(const void* shadow, void* wd, const int* table, int nconv, int tiles, hipStream_t s);
 int vc_ew_bn_bwd_reduce_pooled(const void* y, const void* dout, const uint8_t* idx, const void* pooled, const float* params,
-                               float* sums,
-                               const VcPoolGeom& g, hipStream_t s);
+                               float* sums, const VcPoolGeom& g, const VcBnBwdFin* fin, hipStream_t s);
 int vc_ew_bn_bwd_apply_pooled(const void* y, const void* dout, const uint8_t* idx, const float* params, const float* coef,
                               void* dy, const VcPoolGeom& g, hipStream_t s);

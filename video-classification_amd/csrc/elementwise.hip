@@ -4,6 +4,7 @@
 // bf16, so every kernel moves 16 bytes (8 channels) per lane and indexes its per-channel
 // parameters by (element index mod C).
 #include "common.h"
+#include "bn_fin.h"
 #include "elementwise.h"
 
 namespace {
@@ -26,25 +27,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, float
                                    float eps, float* params) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int r = 0; r < VC_STAT_REPLICAS; ++r) {
-        s += stats[(size_t)r * 2 * C + c];
-        q += stats[(size_t)r * 2 * C + C + c];
-    }
-    const float mean = s / count;
-    float var = q / count - mean * mean;
-    var = var > 0.f ? var : 0.f;
-    const float invstd = rsqrtf(var + eps);
-    const float scale = gamma[c] * invstd;
-    params[c] = mean;
-    params[C + c] = invstd;
-    params[2 * C + c] = scale;
-    params[3 * C + c] = beta[c] - mean * scale;
-    if (running_mean != nullptr) {
-        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-    }
+    vc_bn_finalize_channel<false>(stats, C, c, count, gamma, beta, running_mean, running_var, momentum, eps, params);
 }
 
 // eval mode: params from running statistics
@@ -106,7 +89,7 @@ template <int MODE, int MASK>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restrict__ y, const bf16x8* __restrict__ dz,
                                                           const bf16x8* __restrict__ aux,
                                                           const float* __restrict__ params, float* sums, long rows,
-                                                          int C, int rows_per_block) {
+                                                          int C, int rows_per_block, VcBnFin ffin, VcBnBwdFin bfin) {
     __shared__ float sm[256 * 17];
     const int groups = C >> 3;             // 8-channel groups per row (<= 256)
     const int rl = 256 / groups;           // row lanes per block
@@ -170,6 +153,8 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restri
             atomicAdd(dst + (k < 8 ? 0 : C) + c, s);
         }
     }
+    if (MODE == 0) vc_bn_fin_last(ffin, sums, C);
+    else vc_bn_bwd_fin_last(bfin, sums, C);
 }
 
 // ------------------------------------------------------------------ split-K finalize
@@ -179,7 +164,7 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ slabs, int splits,
                                                               long long stride, bf16x8* __restrict__ out,
                                                               int accumulate, float* stats, long rows, int C,
-                                                              int rows_per_block) {
+                                                              int rows_per_block, VcBnFin fin) {
     __shared__ float sm[STATS ? 256 * 17 : 1];
     const int groups = C >> 3;
     const int rl = 256 / groups;
@@ -237,6 +222,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
                 atomicAdd(dst + (k < 8 ? 0 : C) + threadIdx.x * 8 + (k & 7), s);
             }
         }
+        vc_bn_fin_last(fin, stats, C);
     }
 }
 
@@ -276,15 +262,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, fl
                                        float* dbeta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int r = 0; r < VC_STAT_REPLICAS; ++r) {
-        s += sums[(size_t)r * 2 * C + c];
-        q += sums[(size_t)r * 2 * C + C + c];
-    }
-    coef[c] = s / count;
-    coef[C + c] = q / count;
-    if (dgamma != nullptr) dgamma[c] += q;
-    if (dbeta != nullptr) dbeta[c] += s;
+    vc_bn_bwd_finalize_channel<false>(sums, C, c, count, coef, dgamma, dbeta);
 }
 
 // BN backward apply: dy = scale * (g - c1 - xhat*c2); optionally writes g (the masked
@@ -528,7 +506,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16* _
                                                                    const uint8_t* __restrict__ idx,
                                                                    const bf16x8* __restrict__ pooled,
                                                                    const float* __restrict__ params, float* sums,
-                                                                   VcPoolGeom g) {
+                                                                   VcPoolGeom g, VcBnBwdFin fin) {
     __shared__ float sm[256 * 17];
     __shared__ int lut[256];  // tap -> input row offset from the window origin
     const int C = g.C, groups = C >> 3;
@@ -614,6 +592,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16* _
             atomicAdd(dst + (k < 8 ? 0 : C) + threadIdx.x * 8 + (k & 7), s);
         }
     }
+    vc_bn_bwd_fin_last(fin, sums, C);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_pooled_kernel(const bf16x8* __restrict__ y,
@@ -967,36 +946,41 @@ static void reduce_geometry(long rows, int C, int& grid, int& rpb) {
     grid = (int)((rows + rpb - 1) / rpb);
 }
 
-int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, hipStream_t s) {
+int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, const VcBnFin* fin, hipStream_t s) {
     int grid, rpb;
     reduce_geometry(rows, C, grid, rpb);
     VC_LAUNCH((chan_reduce_kernel<0, 0>), dim3(grid), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)nullptr,
-                       (const bf16x8*)nullptr, (const float*)nullptr, sums, rows, C, rpb);
+                       (const bf16x8*)nullptr, (const float*)nullptr, sums, rows, C, rpb, fin ? *fin : VcBnFin{},
+                       VcBnBwdFin{});
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums, long rows,
-                        int C, int mask, hipStream_t s) {
+                        int C, int mask, const VcBnBwdFin* fin, hipStream_t s) {
     int grid, rpb;
     reduce_geometry(rows, C, grid, rpb);
     const bf16x8 *yy = (const bf16x8*)y, *dd = (const bf16x8*)dz, *aa = (const bf16x8*)aux;
+    const VcBnBwdFin bf = fin ? *fin : VcBnBwdFin{};
     if (mask == 0)
-        VC_LAUNCH((chan_reduce_kernel<1, 0>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
+        VC_LAUNCH((chan_reduce_kernel<1, 0>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb,
+                  VcBnFin{}, bf);
     else if (mask == 1)
-        VC_LAUNCH((chan_reduce_kernel<1, 1>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
+        VC_LAUNCH((chan_reduce_kernel<1, 1>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb,
+                  VcBnFin{}, bf);
     else
-        VC_LAUNCH((chan_reduce_kernel<1, 2>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb);
+        VC_LAUNCH((chan_reduce_kernel<1, 2>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb,
+                  VcBnFin{}, bf);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void* out, int accumulate, float* stats,
-                          long rows, int C, hipStream_t s) {
+                          long rows, int C, const VcBnFin* fin, hipStream_t s) {
     int grid, rpb;
     reduce_geometry(rows, C, grid, rpb);
     if (stats)
         VC_LAUNCH((splitk_finalize_kernel<true>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
-                  accumulate, stats, rows, C, rpb);
+                  accumulate, stats, rows, C, rpb, fin ? *fin : VcBnFin{});
     else
         VC_LAUNCH((splitk_finalize_kernel<false>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
-                  accumulate, stats, rows, C, rpb);
+                  accumulate, stats, rows, C, rpb, VcBnFin{});
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, hipStream_t s) {
@@ -1133,10 +1117,10 @@ int vc_ew_pack_dgrad_batched(const void* shadow, void* wd, const int* table, int
 }
 
 int vc_ew_bn_bwd_reduce_pooled(const void* y, const void* dout, const uint8_t* idx, const void* pooled, const float* params, float* sums,
-                               const VcPoolGeom& g, hipStream_t s) {
+                               const VcPoolGeom& g, const VcBnBwdFin* fin, hipStream_t s) {
     const long total = (long)g.N * g.To * g.Ho * g.Wo * (g.C / 8);
     VC_LAUNCH(bn_bwd_reduce_pooled_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, s, (const bf16*)y,
-              (const bf16x8*)dout, idx, (const bf16x8*)pooled, params, sums, g);
+              (const bf16x8*)dout, idx, (const bf16x8*)pooled, params, sums, g, fin ? *fin : VcBnBwdFin{});
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_bwd_apply_pooled(const void* y, const void* dout, const uint8_t* idx, const float* params, const float* coef,

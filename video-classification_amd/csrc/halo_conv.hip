@@ -471,6 +471,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     }
     VC_STAMP(6);
+    vc_bn_fin_last(p.fin, p.stats, p.Cn);
 }
 
 // LDS bytes of a workgroup: ring + zero row + the larger of the image and the epilogue staging area

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
             }
         }
     }
+    if (p.partial == nullptr) vc_bn_fin_last(p.fin, p.stats, p.Cn);
 }
 
 template <int BCO, int BM, int MODE>

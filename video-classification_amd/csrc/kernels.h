@@ -1,12 +1,14 @@
 // Internal launch interfaces between capi.hip and the kernel translation units.
 #pragma once
 #include "common.h"
+#include "bn_fin.h"
 
 struct VcIgemmParams {
     const bf16* src;  // [N][Ts][Hs][Ws][Cs]
     const bf16* wgt;  // [Cn][Kw]
     bf16* out;
     float* stats;  // nullable: [VC_STAT_REPLICAS][2][Cn]
+    VcBnFin fin;   // fin.ticket nullable: the last workgroup finalizes the BatchNorm parameters (bn_fin.h)
     int M, Ta, Ha, Wa;
     VcFastDiv dWa, dHa, dTa;
     int Ts, Hs, Ws, Cs;
@@ -53,6 +55,7 @@ struct VcHaloParams {
     const bf16* wgt;  // [Cn][Kw]
     bf16* out;        // [NP*H*W][Cn]
     float* stats;     // nullable: [VC_STAT_REPLICAS][2][Cn]
+    VcBnFin fin;      // fin.ticket nullable: the last workgroup finalizes the BatchNorm parameters (bn_fin.h)
     int NP, T, H, W;  // NP = N*T planes of H*W rows
     int Cs, Cn, Kw, ntaps;
     int TT, SEG, HR, halo_rows, npieces, ntg, nseg;  // filled by vc_launch_halo from the plan
@@ -110,6 +113,7 @@ struct VcStemFwdParams {
     const bf16* ws;  // [64][1344]
     bf16* y;         // [N*T*Ho*Wo][64]
     float* stats;    // nullable: [VC_STAT_REPLICAS][2][64]
+    VcBnFin fin;     // fin.ticket nullable: the last workgroup finalizes the BatchNorm parameters (bn_fin.h)
     int N, T, Ho, Wo, Tp, Hp, Wp;
     int RH;          // output rows per chunk (RH * Wo <= 224)
     int TR, nhg, ntr, units;

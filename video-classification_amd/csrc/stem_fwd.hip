@@ -220,6 +220,7 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2
             atomicAdd(srep + (tid < 64 ? 0 : 64) + (tid & 63), s);
         }
     }
+    vc_bn_fin_last(p.fin, p.stats, 64);
 }
 
 }  // namespace

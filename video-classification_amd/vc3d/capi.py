@@ -43,6 +43,13 @@ class PoolDesc(C.Structure):
                 (self.W + 2 * self.pw - self.kw) // self.sw + 1)
 
 
+class BnFin(C.Structure):
+    """vc_bn_fin: BatchNorm finalize folded into the launch that produces the sums (include/vc3d.h)."""
+    _fields_ = [("ticket", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("params", C.c_void_p), ("count", C.c_float), ("momentum", C.c_float),
+                ("eps", C.c_float)]
+
+
 _P = C.c_void_p
 _I = C.c_int32
 _L = C.c_int64
@@ -50,6 +57,7 @@ _F = C.c_float
 _CD = C.POINTER(ConvDesc)
 _PD = C.POINTER(PoolDesc)
 _IP = C.POINTER(C.c_int32)
+_BF = C.POINTER(BnFin)
 
 # name -> argtypes (every function returns int unless listed in _RESTYPE)
 PROTOTYPES = {
@@ -58,6 +66,7 @@ PROTOTYPES = {
     "vc_conv3d_out_dims": [_CD, _IP, _IP, _IP],
     "vc_conv3d_workspace_bytes": [_CD, _I],
     "vc_conv3d_fwd": [_CD, _P, _P, _P, _P, _P, C.c_size_t, _P],
+    "vc_conv3d_fwd_bn": [_CD, _P, _P, _P, _P, _BF, _P, C.c_size_t, _P],
     "vc_conv3d_dgrad": [_CD, _P, _P, _P, _I, _P, C.c_size_t, _P],
     "vc_conv3d_wgrad": [_CD, _P, _P, _P, _P, C.c_size_t, _P],
     "vc_pack_weight": [_P, _P, _P, _I, _I, _I, _P],
@@ -68,6 +77,7 @@ PROTOTYPES = {
     "vc_stem_pack_input": [_P, _I, _P, _I, _I, _I, _I, _P],
     "vc_stem_pack_weight": [_P, _P, _I, _P],
     "vc_stem_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vc_stem_fwd_bn": [_P, _P, _P, _P, _BF, _I, _I, _I, _I, _I, _P],
     "vc_stem_wgrad_workspace_bytes": [_I, _I, _I, _I, _I],
     "vc_stem_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P, C.c_size_t, _P],
     "vc_stem_unpack_wgrad": [_P, _P, _I, _P],
@@ -76,6 +86,7 @@ PROTOTYPES = {
     "vc_bn_eval_params": [_I, _P, _P, _P, _P, _F, _P, _P],
     "vc_bn_apply": [_P, _P, _P, _P, _L, _I, _I, _P],
     "vc_bn_bwd_reduce": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "vc_bn_bwd_reduce_fin": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P],
     "vc_bn_bwd_finalize": [_P, _I, _F, _P, _P, _P, _P],
     "vc_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "vc_add": [_P, _P, _P, _L, _P],
@@ -83,6 +94,7 @@ PROTOTYPES = {
     "vc_maxpool3d_fwd": [_PD, _P, _P, _P, _P, _P],
     "vc_maxpool3d_bwd": [_PD, _P, _P, _P, _P],
     "vc_bn_bwd_reduce_pooled": [_PD, _P, _P, _P, _P, _P, _P, _P],
+    "vc_bn_bwd_reduce_pooled_fin": [_PD, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "vc_bn_bwd_apply_pooled": [_PD, _P, _P, _P, _P, _P, _P, _P],
     "vc_gavgpool_fwd": [_P, _P, _I, _I, _I, _P],
     "vc_gavgpool_bwd": [_P, _P, _I, _I, _I, _P],

@@ -19,6 +19,7 @@ import os
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+FUSED_BN_FIN = os.environ.get("VC_NO_BN_FIN") is None  # BatchNorm finalize done by the last workgroup of the producer
 SIDE_WGRAD = os.environ.get("VC_WGRAD_SIDE_STREAM", "1") != "0"  # weight gradients on a side stream (engine._wgrad)
 
 
@@ -87,6 +88,8 @@ class R3DEngine:
         self._main = None          # the stream backward was issued on (what a bucket all-reduce must also wait for)
         self.backward_done_cb = None
         self._stem_scratch = None
+        self._tickets = None       # zero int32 words of the fused BatchNorm finalize (see _ticket)
+        self._ticket_ix = None
         self.trace = None  # tests set this to {} to record every intermediate tensor per layer
 
     def _t(self, name, **kw):
@@ -239,6 +242,32 @@ class R3DEngine:
         h.record_stream(self._side)
 
     # ------------------------------------------------------------------ forward
+    def _ticket(self, cb, bwd):
+        """one zero int32 word per BatchNorm layer and direction (the fused finalize leaves it zero)."""
+        dev = cb.bn.weight.device
+        if self._tickets is None or self._tickets.device != dev:
+            self._ticket_ix = {id(c): i for i, c in enumerate(self.all_convbn())}
+            self._tickets = torch.zeros(2 * len(self._ticket_ix), dtype=torch.int32, device=dev)
+        i = 2 * self._ticket_ix[id(cb)] + (1 if bwd else 0)
+        return self._tickets[i:i + 1]
+
+    def _bticket(self, cb):
+        return self._ticket(cb, True) if FUSED_BN_FIN else None
+
+    def _bn_fin(self, cb, count):
+        """descriptor of the training-mode finalize folded into the conv launch, or None."""
+        bn = cb.bn
+        if not FUSED_BN_FIN:
+            return None, None
+        if bn.momentum is None:
+            raise Vc3dError("cumulative-average BatchNorm (momentum=None) is not supported")
+        fin, p = ops.bn_fin(self._ticket(cb, False), count, bn.weight.detach(), bn.bias.detach(),
+                            bn.running_mean if bn.track_running_stats else None,
+                            bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps)
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            self._nbt.append(bn.num_batches_tracked)
+        return fin, p
+
     def _bn_params(self, cb, stats, count, training):
         bn = cb.bn
         if training:
@@ -261,9 +290,12 @@ class R3DEngine:
         d = cb.desc(x)
         wf, _ = cb.weights()
         stats = stats_pool.take(cb.Co) if training else None
-        y = ops.conv3d_fwd(d, x, wf, stats=stats)
-        count = y.numel() // cb.Co
-        params = self._bn_params(cb, stats, count, training)
+        To, Ho, Wo = d.out_dims()
+        count = d.N * To * Ho * Wo
+        fin, params = self._bn_fin(cb, count) if training else (None, None)
+        y = ops.conv3d_fwd(d, x, wf, stats=stats, fin=fin)
+        if fin is None:
+            params = self._bn_params(cb, stats, count, training)
         return d, y, params
 
     def forward(self, x, training, save):
@@ -286,8 +318,10 @@ class R3DEngine:
             self.stem_wver = (w._version, self.param_epoch)
         xs = ops.stem_pack_input(x)
         stats0 = stats_pool.take(st.Co) if training else None
-        y0 = ops.stem_fwd(xs, self.stem_ws, N, T, H, W, st.Co, stats=stats0)
-        p0 = self._bn_params(st, stats0, y0.numel() // st.Co, training)
+        fin0, p0 = self._bn_fin(st, N * T * (H // 2) * (W // 2)) if training else (None, None)
+        y0 = ops.stem_fwd(xs, self.stem_ws, N, T, H, W, st.Co, stats=stats0, fin=fin0)
+        if fin0 is None:
+            p0 = self._bn_params(st, stats0, y0.numel() // st.Co, training)
         pk, ps, pp = self.pool
         pd = ops.pool_desc(N, st.Co, T, H // 2, W // 2, pk, ps, pp)
         a0, idx = ops.maxpool3d_fwd(pd, y0, p0)
@@ -347,7 +381,7 @@ class R3DEngine:
             cb = cbs[-1]
             d, h, y, prm, out = recs[-1]
             dy, gres = ops.bn_bwd(y, g, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias), mask=1,
-                                  aux=out, want_g=True, sums=sums_pool.take(cb.Co))
+                                  aux=out, want_g=True, sums=sums_pool.take(cb.Co), ticket=self._bticket(cb))
             self._ready(cb.bn.weight, cb.bn.bias)
             self._wgrad(d, h, dy, cb.conv)
             _, wd = cb.weights()
@@ -361,13 +395,13 @@ class R3DEngine:
                 # BN -> ReLU with nothing in between: the ReLU mask is recomputed from y (scale * y + shift > 0,
                 # the forward's own expression) instead of reading the activation z a third tensor per pass
                 dy, _ = ops.bn_bwd(y, dz, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias), mask=2,
-                                   sums=sums_pool.take(cb.Co))
+                                   sums=sums_pool.take(cb.Co), ticket=self._bticket(cb))
                 self._ready(cb.bn.weight, cb.bn.bias)
                 if i == 0 and ds is not None:
                     # downsample branch first so the first conv's dgrad can accumulate onto it
                     dd, yd, prmd = dsrec
                     dyd, _ = ops.bn_bwd(yd, gres, prmd, ds.Co, self.gview(ds.bn.weight), self.gview(ds.bn.bias),
-                                        mask=0, sums=sums_pool.take(ds.Co))
+                                        mask=0, sums=sums_pool.take(ds.Co), ticket=self._bticket(ds))
                     self._ready(ds.bn.weight, ds.bn.bias)
                     self._wgrad(dd, xin, dyd, ds.conv)
                     _, wdd = ds.weights()
@@ -396,10 +430,10 @@ class R3DEngine:
             self._t("conv1", dpooled=g, dz=din)
         if all(k <= 2 * s for k, s in zip(self.pool[0], self.pool[1])):
             dy0 = ops.bn_bwd_pooled(pd, y0, g, idx, p0, st.Co, self.gview(st.bn.weight), self.gview(st.bn.bias),
-                                    sums=sums_pool.take(st.Co), pooled=a0)
+                                    sums=sums_pool.take(st.Co), pooled=a0, ticket=self._bticket(st))
         else:  # windows overlapping more than twice per axis: materialise the pool-input gradient
             dy0, _ = ops.bn_bwd(y0, ops.maxpool3d_bwd(pd, g, idx), p0, st.Co, self.gview(st.bn.weight),
-                                self.gview(st.bn.bias), mask=2, sums=sums_pool.take(st.Co))
+                                self.gview(st.bn.bias), mask=2, sums=sums_pool.take(st.Co), ticket=self._bticket(st))
         self._ready(st.bn.weight, st.bn.bias)
         if self._stem_scratch is None or self._stem_scratch.device != dev or self._stem_scratch.shape[0] != st.Co:
             self._stem_scratch = torch.zeros(st.Co, ops.STEM_K, dtype=F32, device=dev)

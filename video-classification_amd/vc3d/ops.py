@@ -108,7 +108,24 @@ def pack_weight(w_master, want_dgrad=True):
     return wf, wd
 
 
-def conv3d_fwd(d, x, wf, stats=None, out=None):
+def bn_fin(ticket, count, gamma, beta, running_mean, running_var, momentum, eps, params=None):
+    """descriptor of a BatchNorm finalize folded into the conv launch that produces the sums (the last workgroup
+    does bn_finalize's work).  `ticket`: one int32 element, zero before its first use (left zero by the launch).
+    Returns (descriptor, params [4][C])."""
+    Cn = gamma.numel()
+    _chk(ticket, torch.int32, 1, "ticket")
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _chk(t, F32, Cn, nm)
+    if params is None:
+        params = torch.empty(4, Cn, dtype=F32, device=gamma.device)
+    _chk(params, F32, 4 * Cn, "bn params")
+    f = capi.BnFin(ptr(ticket), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(params), float(count),
+                   float(momentum), float(eps))
+    f._keep = (ticket, gamma, beta, running_mean, running_var, params)
+    return f, params
+
+
+def conv3d_fwd(d, x, wf, stats=None, out=None, fin=None):
     To, Ho, Wo = d.out_dims()
     taps = d.kt * d.kh * d.kw
     _chk(x, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "x")
@@ -119,7 +136,11 @@ def conv3d_fwd(d, x, wf, stats=None, out=None):
     _chk(stats, F32, VC_STAT_REPLICAS * 2 * d.Co, "bn_stats")
     ev = TIMER.begin(_conv_key("fwd", d), _conv_flops(d)) if TIMER is not None else None
     ws, wsb = _workspace(d, 0, x.device)
-    check(lib.vc_conv3d_fwd(d, ptr(x), ptr(wf), ptr(out), ptr(stats), ws, wsb, cur_stream()), "vc_conv3d_fwd")
+    if fin is not None:
+        check(lib.vc_conv3d_fwd_bn(d, ptr(x), ptr(wf), ptr(out), ptr(stats), fin, ws, wsb, cur_stream()),
+              "vc_conv3d_fwd_bn")
+    else:
+        check(lib.vc_conv3d_fwd(d, ptr(x), ptr(wf), ptr(out), ptr(stats), ws, wsb, cur_stream()), "vc_conv3d_fwd")
     if ev is not None:
         ev.record()
     return out
@@ -221,7 +242,7 @@ def stem_pack_weight(w_master):
     return ws
 
 
-def stem_fwd(xs, ws, N, T, H, W, Co, stats=None, out=None):
+def stem_fwd(xs, ws, N, T, H, W, Co, stats=None, out=None, fin=None):
     _chk(xs, BF16, N * (T + 6) * (H // 2 + 3) * stem_wp(W) * 12, "xs")
     _chk(ws, BF16, Co * STEM_K, "ws")
     if out is None:
@@ -230,7 +251,11 @@ def stem_fwd(xs, ws, N, T, H, W, Co, stats=None, out=None):
     _chk(stats, F32, VC_STAT_REPLICAS * 2 * Co, "bn_stats")
     flops = 2.0 * N * T * (H // 2) * (W // 2) * Co * 1029
     ev = TIMER.begin(("stem_fwd", N, T, H, W, Co), flops) if TIMER is not None else None
-    check(lib.vc_stem_fwd(ptr(xs), ptr(ws), ptr(out), ptr(stats), N, T, H, W, Co, cur_stream()), "vc_stem_fwd")
+    if fin is not None:
+        check(lib.vc_stem_fwd_bn(ptr(xs), ptr(ws), ptr(out), ptr(stats), fin, N, T, H, W, Co, cur_stream()),
+              "vc_stem_fwd_bn")
+    else:
+        check(lib.vc_stem_fwd(ptr(xs), ptr(ws), ptr(out), ptr(stats), N, T, H, W, Co, cur_stream()), "vc_stem_fwd")
     if ev is not None:
         ev.record()
     return out
@@ -306,8 +331,9 @@ def bn_apply(y, params, C, residual=None, relu=True, out=None):
 
 
 def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=False, sums=None, coef=None,
-           dy=None, g_out=None):
-    """BatchNorm backward (batch statistics).  Returns (dy, g) with g = masked dz or None."""
+           dy=None, g_out=None, ticket=None):
+    """BatchNorm backward (batch statistics).  Returns (dy, g) with g = masked dz or None.
+    `ticket` (one zero int32 element): the reduction's last workgroup does the finalize (one launch less)."""
     n = y.numel()
     _chk(y, BF16, name="y")
     _chk(dz, BF16, n, "dz")
@@ -329,16 +355,21 @@ def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=Fal
         g_out = torch.empty_like(y)
     _chk(g_out, BF16, n, "g_out")
     s = cur_stream()
-    check(lib.vc_bn_bwd_reduce(ptr(y), ptr(dz), ptr(aux), ptr(params), ptr(sums), rows, C, mask, s),
-          "vc_bn_bwd_reduce")
-    check(lib.vc_bn_bwd_finalize(ptr(sums), C, float(rows), ptr(coef), ptr(gamma_grad), ptr(beta_grad), s),
-          "vc_bn_bwd_finalize")
+    if ticket is not None:
+        _chk(ticket, torch.int32, 1, "ticket")
+        check(lib.vc_bn_bwd_reduce_fin(ptr(y), ptr(dz), ptr(aux), ptr(params), ptr(sums), rows, C, mask, ptr(ticket),
+                                       ptr(coef), ptr(gamma_grad), ptr(beta_grad), s), "vc_bn_bwd_reduce_fin")
+    else:
+        check(lib.vc_bn_bwd_reduce(ptr(y), ptr(dz), ptr(aux), ptr(params), ptr(sums), rows, C, mask, s),
+              "vc_bn_bwd_reduce")
+        check(lib.vc_bn_bwd_finalize(ptr(sums), C, float(rows), ptr(coef), ptr(gamma_grad), ptr(beta_grad), s),
+              "vc_bn_bwd_finalize")
     check(lib.vc_bn_bwd_apply(ptr(y), ptr(dz), ptr(aux), ptr(params), ptr(coef), ptr(dy), ptr(g_out), n, C, mask, s),
           "vc_bn_bwd_apply")
     return dy, g_out
 
 
-def bn_bwd_pooled(pd, y, dpooled, idx, params, C, gamma_grad, beta_grad, sums=None, pooled=None):
+def bn_bwd_pooled(pd, y, dpooled, idx, params, C, gamma_grad, beta_grad, sums=None, pooled=None, ticket=None):
     """BN+ReLU backward of the stem straight from the max-pool output gradient (no materialised
     pool-input gradient).  Returns dy (gradient of the conv output).  `pooled` = the pool's output
     (maxpool3d_fwd with the same params): lets the reduction skip its element-wise gather of y."""
@@ -359,10 +390,16 @@ def bn_bwd_pooled(pd, y, dpooled, idx, params, C, gamma_grad, beta_grad, sums=No
     coef = torch.empty(2, C, dtype=F32, device=y.device)
     dy = torch.empty_like(y)
     s = cur_stream()
-    check(lib.vc_bn_bwd_reduce_pooled(pd, ptr(y), ptr(dpooled), ptr(idx), ptr(pooled), ptr(params), ptr(sums), s),
-          "vc_bn_bwd_reduce_pooled")
-    check(lib.vc_bn_bwd_finalize(ptr(sums), C, float(n // C), ptr(coef), ptr(gamma_grad), ptr(beta_grad), s),
-          "vc_bn_bwd_finalize")
+    if ticket is not None:
+        _chk(ticket, torch.int32, 1, "ticket")
+        check(lib.vc_bn_bwd_reduce_pooled_fin(pd, ptr(y), ptr(dpooled), ptr(idx), ptr(pooled), ptr(params), ptr(sums),
+                                              ptr(ticket), ptr(coef), ptr(gamma_grad), ptr(beta_grad), s),
+              "vc_bn_bwd_reduce_pooled_fin")
+    else:
+        check(lib.vc_bn_bwd_reduce_pooled(pd, ptr(y), ptr(dpooled), ptr(idx), ptr(pooled), ptr(params), ptr(sums), s),
+              "vc_bn_bwd_reduce_pooled")
+        check(lib.vc_bn_bwd_finalize(ptr(sums), C, float(n // C), ptr(coef), ptr(gamma_grad), ptr(beta_grad), s),
+              "vc_bn_bwd_finalize")
     check(lib.vc_bn_bwd_apply_pooled(pd, ptr(y), ptr(dpooled), ptr(idx), ptr(params), ptr(coef), ptr(dy), s),
           "vc_bn_bwd_apply_pooled")
     return dy
