@@ -108,6 +108,16 @@ int vc_pack_dgrad_batched(const void* shadow_bf16, void* w_dgrad_flat, const int
 size_t vc_stem_packed_input_elems(int32_t N, int32_t T, int32_t H, int32_t W);
 int vc_stem_pack_input(const void* x, int32_t x_is_bf16, void* xs, int32_t N, int32_t T, int32_t H,
                        int32_t W, void* stream);
+/* Clip input pipeline (the reference's get_dataset, lib/dataset/dataset.py:6-12, is empty and
+ * its loop takes ready clips at lib/core/function.py:58,68): decoded uint8 RGB frames [N][Ts][Hs][Ws][3] ->
+ * temporal sampling (frame t0 + t*tstep), spatial crop at (y0, x0), optional horizontal flip, per-channel
+ * normalisation v = u8 * (1 / (255 std[c])) - mean[c] / std[c] (one fp32 fma), rounded to bf16 and written
+ * straight into the packed stem source of vc_stem_pack_input (same layout, same padding) in one pass.
+ * crops: int32 [N][4] = {t0, y0, x0, flip}, the same table on the device and on the host (validated on the host:
+ * the kernel does no bounds tests); mean/std: 3 host floats each, in units of u8/255. */
+int vc_clip_pack_u8(const uint8_t* frames, const int32_t* crops_dev, const int32_t* crops_host, void* xs,
+                    int32_t N, int32_t T, int32_t H, int32_t W, int32_t Ts, int32_t Hs, int32_t Ws,
+                    int32_t tstep, const float* mean, const float* std, void* stream);
 int vc_stem_pack_weight(const float* w_master /* [Co][7][7][7][3] */, void* ws, int32_t Co, void* stream);
 int vc_stem_fwd(const void* xs, const void* ws, void* y /* [N][T][H/2][W/2][Co] */, float* bn_stats,
                 int32_t N, int32_t T, int32_t H, int32_t W, int32_t Co, void* stream);

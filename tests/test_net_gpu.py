@@ -133,3 +133,26 @@ def test_cpu_input_raises():
     _, prod, _ = build_pair(18, 101)
     with pytest.raises(Vc3dError):
         prod(torch.zeros(1, 3, 4, 32, 32))
+
+
+def test_packed_uint8_clips_give_the_float_path_logits():
+    """the model takes ops.clip_pack_u8's PackedClips in place of the float clip tensor: same logits as feeding the
+    torch-normalised float clip (both round the same values to bf16; <= 1 ulp differences in a handful of inputs)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    from vc3d import ops
+    _, prod, _ = build_pair(18, 11, device="cuda:0")
+    prod.eval()
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (2, 12, 40, 48, 3), generator=g, dtype=torch.uint8)
+    crops = torch.tensor([[1, 3, 5, 0], [0, 8, 16, 1]], dtype=torch.int32)
+    mean, std = (0.45, 0.45, 0.45), (0.225, 0.225, 0.225)
+    pc = ops.clip_pack_u8(frames.cuda(), crops, 8, 32, 32, 1, mean, std)
+    x = torch.stack([((frames[n, c[0]:c[0] + 8, c[1]:c[1] + 32, c[2]:c[2] + 32].float() / 255.0
+                       - torch.tensor(mean)) / torch.tensor(std)).permute(3, 0, 1, 2) for n, c in enumerate(crops.tolist())])
+    x[1] = x[1].flip(-1)
+    with torch.no_grad():
+        _, lo_u8, _ = prod(pc)
+        _, lo_f, _ = prod(x.cuda())
+    torch.cuda.synchronize()
+    assert rel_l2(lo_u8, lo_f) <= 2e-3

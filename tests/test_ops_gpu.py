@@ -409,3 +409,71 @@ def test_bn_bwd_through_pool_matches_unfused(shape):
         bn.bias.copy_(beta)
     F.max_pool3d(bf16_round(torch.relu(bn(yr)).detach()) + (torch.relu(bn(yr)) - torch.relu(bn(yr)).detach()), 3, 2, 1).backward(dp)
     assert rel_l2(from_nthwc(dy1), yr.grad) <= 2e-2
+
+
+def _clip_pack_reference(frames, crops, T, H, W, tstep, mean, std):
+    """torch restatement of vc_clip_pack_u8 up to (not including) the stem packing: N x 3 x T x H x W fp32,
+    v = fma(u8, 1/(255 std), -mean/std) in fp32."""
+    N = frames.shape[0]
+    out = torch.empty(N, 3, T, H, W)
+    a = 1.0 / (255.0 * torch.tensor(std, dtype=torch.float32))
+    b = -torch.tensor(mean, dtype=torch.float32) / torch.tensor(std, dtype=torch.float32)
+    for n in range(N):
+        t0, y0, x0, flip = [int(v) for v in crops[n]]
+        c = frames[n, t0:t0 + (T - 1) * tstep + 1:tstep, y0:y0 + H, x0:x0 + W, :].float()  # T H W 3
+        if flip:
+            c = c.flip(2)
+        out[n] = torch.addcmul(b.view(1, 1, 1, 3), c, a.view(1, 1, 1, 3)).permute(3, 0, 1, 2)
+    return out
+
+
+@pytest.mark.parametrize("geom", [
+    # N, Ts, Hs, Ws, T, H, W, tstep
+    (2, 9, 20, 28, 4, 16, 16, 2),
+    (3, 5, 12, 20, 5, 12, 20, 1),    # crop = whole frame
+    (1, 33, 128, 171, 16, 112, 112, 2),  # the usual 128x171 -> 112x112 training crop, every other frame
+])
+def test_clip_pack_u8_matches_torch_and_float_path(geom):
+    """uint8 frames -> sampled / cropped / flipped / normalised bf16 in the stem's packed form.
+    Bar: the packed source equals stem_pack_input of the torch restatement to <= 1 bf16 ulp (the kernel's single
+    fp32 fma vs torch's addcmul may round the last fp32 bit differently before the bf16 rounding), padding exactly 0."""
+    _need_gpu()
+    from vc3d import ops
+    N, Ts, Hs, Ws, T, H, W, tstep = geom
+    g = torch.Generator().manual_seed(N * 100 + Ts)
+    frames = torch.randint(0, 256, (N, Ts, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    crops = torch.zeros(N, 4, dtype=torch.int32)
+    for n in range(N):
+        crops[n, 0] = int(torch.randint(0, Ts - (T - 1) * tstep, (1,), generator=g))
+        crops[n, 1] = int(torch.randint(0, Hs - H + 1, (1,), generator=g))
+        crops[n, 2] = int(torch.randint(0, Ws - W + 1, (1,), generator=g))
+        crops[n, 3] = n % 2
+    if N > 1:
+        crops[1, 3] = 1
+    mean, std = (0.43, 0.40, 0.37), (0.23, 0.22, 0.25)
+    pc = ops.clip_pack_u8(frames.cuda(), crops, T, H, W, tstep, mean, std)
+    ref = _clip_pack_reference(frames, crops, T, H, W, tstep, mean, std)
+    xs_ref = ops.stem_pack_input(ref.cuda())
+    torch.cuda.synchronize()
+    assert pc.shape == (N, 3, T, H, W)
+    a, b = pc.xs.float().cpu(), xs_ref.float().cpu()
+    assert torch.equal(a == 0, b == 0) or float((a - b).abs().max()) < 1e-2  # same zero padding
+    ulp = torch.maximum(b.abs(), torch.tensor(1e-30)) * 2.0 ** -7
+    assert bool(((a - b).abs() <= ulp).all()), float(((a - b).abs() / ulp).max())
+    assert float((a != b).float().mean()) < 1e-3  # and all but a handful are identical
+
+
+def test_clip_pack_u8_rejects_bad_tables():
+    _need_gpu()
+    from vc3d import ops
+    from vc3d.capi import Vc3dError
+    frames = torch.zeros(1, 8, 20, 20, 3, dtype=torch.uint8, device="cuda")
+    ok = torch.tensor([[0, 2, 2, 0]], dtype=torch.int32)
+    ops.clip_pack_u8(frames, ok, 4, 16, 16, 2)
+    for bad in ([2, 0, 0, 0], [0, 5, 0, 0], [0, 0, 5, 0], [0, 0, 0, 2], [-1, 0, 0, 0]):
+        with pytest.raises(Vc3dError):
+            ops.clip_pack_u8(frames, torch.tensor([bad], dtype=torch.int32), 4, 16, 16, 2)
+    with pytest.raises(Vc3dError):
+        ops.clip_pack_u8(frames.cpu(), ok, 4, 16, 16, 2)
+    with pytest.raises(Vc3dError):
+        ops.clip_pack_u8(frames, ok, 4, 16, 16, 2, std=(1.0, 0.0, 1.0))

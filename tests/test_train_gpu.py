@@ -125,3 +125,37 @@ def test_flat_sgd_matches_torch_sgd(nesterov):
     loss.backward()
     opt.step()
     assert torch.isfinite(loss)
+
+
+def test_train_and_validate_on_raw_uint8_frames(monkeypatch):
+    """the loops take decoded uint8 frames; ChooseInput samples / crops / normalises them on the
+    GPU (vc_clip_pack_u8) and the model consumes the packed clips directly."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    monkeypatch.syspath_prepend(PKG)
+    from core.config import config as cfg
+    from core.function import train, validate
+    from core.loss import Loss
+    from dataset.dataset import SyntheticFrames
+    from models.model import create_model
+    from utils.utils import create_optimizer
+    keep = (cfg.MODEL.INIT_WEIGHTS, cfg.MODEL.CLFDIM, cfg.MODEL.CLIP_LEN, cfg.MODEL.CROP_SIZE, cfg.MODEL.FRAME_STEP,
+            cfg.TRAIN.TRAIN_STEP, cfg.TRAIN.OPTIMIZER, cfg.TRAIN.LR)
+    try:
+        cfg.MODEL.INIT_WEIGHTS, cfg.MODEL.CLFDIM, cfg.MODEL.CLIP_LEN, cfg.MODEL.CROP_SIZE = False, 4, 4, 32
+        cfg.MODEL.FRAME_STEP, cfg.TRAIN.TRAIN_STEP, cfg.TRAIN.OPTIMIZER, cfg.TRAIN.LR = 2, 1, 'sgd', 0.01
+        torch.manual_seed(0)
+        model = create_model(cfg, is_train=True).cuda()
+        crit = Loss(cfg).cuda()
+        opt = create_optimizer(cfg, model)
+        ds = SyntheticFrames(8, frames=9, height=40, width=52, classes=4)
+        loader = torch.utils.data.DataLoader(ds, batch_size=4)
+        w0 = model.backbone.conv1.weight.detach().clone()
+        train(cfg, loader, model, crit, opt, 0)
+        torch.cuda.synchronize()
+        assert not torch.equal(w0, model.backbone.conv1.weight.detach())
+        acc = validate(cfg, loader, model, crit, 0)
+        assert 0.0 <= acc <= 1.0
+    finally:
+        (cfg.MODEL.INIT_WEIGHTS, cfg.MODEL.CLFDIM, cfg.MODEL.CLIP_LEN, cfg.MODEL.CROP_SIZE, cfg.MODEL.FRAME_STEP,
+         cfg.TRAIN.TRAIN_STEP, cfg.TRAIN.OPTIMIZER, cfg.TRAIN.LR) = keep

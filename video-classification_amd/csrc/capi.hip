@@ -575,6 +575,31 @@ int vc_stem_pack_input(const void* x, int32_t x_is_bf16, void* xs, int32_t N, in
     return vc_ew_stem_pack_input(x, x_is_bf16, xs, N, T, H, W, S(stream));
 }
 
+int vc_clip_pack_u8(const uint8_t* frames, const int32_t* crops_dev, const int32_t* crops_host, void* xs, int32_t N,
+                    int32_t T, int32_t H, int32_t W, int32_t Ts, int32_t Hs, int32_t Ws, int32_t tstep,
+                    const float* mean, const float* std, void* stream) {
+    int rc = stem_check(N, T, H, W, 64);
+    if (rc) return rc;
+    VC_REQUIRE(frames && crops_dev && crops_host && xs && mean && std, "clip_pack_u8: null pointer");
+    VC_REQUIRE(Ts > 0 && Hs >= H && Ws >= W && tstep >= 1, "clip_pack_u8: source %dx%dx%d smaller than the crop", Ts, Hs,
+               Ws);
+    VC_REQUIRE((long long)N * Ts * Hs * Ws * 3 < (1ll << 40), "clip_pack_u8: source too large");
+    // every read is checked here, on the host copy of the table: the kernel does no bounds tests
+    for (int n = 0; n < N; ++n) {
+        const int32_t* c = crops_host + 4 * n;
+        VC_REQUIRE(c[0] >= 0 && (long long)c[0] + (long long)(T - 1) * tstep < Ts, "clip_pack_u8: clip %d: frames %d + %d*%d leave the video (%d frames)", n, c[0], T - 1, tstep, Ts);
+        VC_REQUIRE(c[1] >= 0 && c[1] + H <= Hs && c[2] >= 0 && c[2] + W <= Ws, "clip_pack_u8: clip %d: crop at (%d, %d) leaves the %d x %d frame", n, c[1], c[2], Hs, Ws);
+        VC_REQUIRE(c[3] == 0 || c[3] == 1, "clip_pack_u8: clip %d: flip must be 0 or 1", n);
+    }
+    float a[3], b[3];
+    for (int c = 0; c < 3; ++c) {
+        VC_REQUIRE(std[c] > 0.f, "clip_pack_u8: std must be positive");
+        a[c] = 1.0f / (255.0f * std[c]);
+        b[c] = -mean[c] / std[c];
+    }
+    return vc_ew_clip_pack_u8(frames, crops_dev, xs, N, T, H, W, Ts, Hs, Ws, tstep, a, b, S(stream));
+}
+
 int vc_stem_pack_weight(const float* w_master, void* ws, int32_t Co, void* stream) {
     VC_REQUIRE(w_master && ws && Co > 0, "stem_pack_weight: bad arguments");
     return vc_ew_stem_pack_weight(w_master, ws, Co, S(stream));

@@ -35,6 +35,8 @@ int vc_ew_linear_fwd(const float* feat, const float* W, const float* bias, float
 int vc_ew_linear_bwd(const float* dlog, const float* feat, const float* W, float* dfeat, float* dW, float* db, int N,
                      int F, int K, hipStream_t s);
 int vc_ew_stem_pack_input(const void* x, int x_is_bf16, void* xs, int N, int T, int H, int W, hipStream_t s);
+int vc_ew_clip_pack_u8(const uint8_t* frames, const int* crops, void* xs, int N, int T, int H, int W, int Ts, int Hs,
+                       int Ws, int tstep, const float* a, const float* b, hipStream_t s);
 int vc_ew_ncs_to_nsc(const void* in, int in_is_bf16, void* out, int N, int C, long S, hipStream_t s);
 int vc_ew_nsc_to_ncs(const void* in, void* out, int out_is_bf16, int N, int C, long S, hipStream_t s);
 int vc_ew_pack_weight(const float* w, void* wf, void* wd, int Co, int taps, int Ci, hipStream_t s);

@@ -728,6 +728,59 @@ __global__ __launch_bounds__(256) void stem_pack_input_kernel(const TIN* __restr
     }
 }
 
+// Clip input pipeline: decoded uint8 frames [N][Ts][Hs][Ws][3] (RGB interleaved, what a video decoder hands over)
+// -> temporal sampling + crop + horizontal flip + per-channel normalisation -> the SAME packed stem source as
+// above, in one pass: v = u8 * a[c] + b[c] (one fp32 fma; a = 1 / (255 std), b = -mean / std), rounded to bf16.
+// crops[n] = {t0, y0, x0, flip}: output (t, h, w) reads frame t0 + t*tstep, row y0 + h, column x0 + (flip ? W-1-w : w).
+// A thread owns one packed position = 2 x 2 pixels: two runs of 6 contiguous source bytes; neighbouring threads
+// read neighbouring runs.  HBM-bound: 3 B read + 6 B written per pixel (+ the zero padding of the packed form).
+__global__ __launch_bounds__(256) void clip_pack_u8_kernel(const uint8_t* __restrict__ frames,
+                                                           const int* __restrict__ crops, bf16* __restrict__ xs, int N,
+                                                           int T, int H, int W, int Ts, int Hs, int Ws, int tstep,
+                                                           float a0, float a1, float a2, float b0, float b1, float b2) {
+    const int Tp = T + 6, Hp = H / 2 + 3, Wp = (W / 2 + 4) & ~1;
+    const long total = (long)N * Tp * Hp * Wp;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const float a[3] = {a0, a1, a2}, b[3] = {b0, b1, b2};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        long pos = i;
+        const int wp = (int)(pos % Wp);
+        pos /= Wp;
+        const int hp = (int)(pos % Hp);
+        pos /= Hp;
+        const int tp = (int)(pos % Tp);
+        const int n = (int)(pos / Tp);
+        const int t = tp - 3, h2 = hp - 2, w2 = wp - 2;
+        bf16 v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = f2bf(0.f);
+        if ((unsigned)t < (unsigned)T && (unsigned)h2 < (unsigned)(H / 2) && (unsigned)w2 < (unsigned)(W / 2)) {
+            const int t0 = crops[n * 4], y0 = crops[n * 4 + 1], x0 = crops[n * 4 + 2], flip = crops[n * 4 + 3];
+            const uint8_t* fr = frames + ((long)n * Ts + (t0 + t * tstep)) * Hs * Ws * 3;
+            // the pixel pair (2*w2, 2*w2+1) of the crop is source columns xl, xl+1 (mirrored pair when flipped)
+            const int xl = flip ? x0 + (W - 2 - 2 * w2) : x0 + 2 * w2;
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh) {
+                const uint8_t* row = fr + ((long)(y0 + 2 * h2 + bh) * Ws + xl) * 3;
+                uint8_t px[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) px[k] = row[k];
+#pragma unroll
+                for (int bw = 0; bw < 2; ++bw)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int sb = flip ? 1 - bw : bw;
+                        v[(bh * 2 + bw) * 3 + c] = f2bf(fmaf((float)px[sb * 3 + c], a[c], b[c]));
+                    }
+            }
+        }
+        bf16x4* dst = (bf16x4*)(xs + i * 12);
+        dst[0] = (bf16x4){v[0], v[1], v[2], v[3]};
+        dst[1] = (bf16x4){v[4], v[5], v[6], v[7]};
+        dst[2] = (bf16x4){v[8], v[9], v[10], v[11]};
+    }
+}
+
 // generic NCTHW (fp32|bf16) <-> NTHWC bf16, S = T*H*W
 template <typename TIN>
 __global__ void ncs_to_nsc_kernel(const TIN* __restrict__ in, bf16* __restrict__ out, int N, int C, long S) {
@@ -1065,6 +1118,13 @@ int vc_ew_stem_pack_input(const void* x, int x_is_bf16, void* xs, int N, int T, 
     else
         VC_LAUNCH((stem_pack_input_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)x,
                            (bf16*)xs, N, T, H, W);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_clip_pack_u8(const uint8_t* frames, const int* crops, void* xs, int N, int T, int H, int W, int Ts, int Hs,
+                       int Ws, int tstep, const float* a, const float* b, hipStream_t s) {
+    const long total = (long)N * (T + 6) * (H / 2 + 3) * ((W / 2 + 4) & ~1);
+    VC_LAUNCH(clip_pack_u8_kernel, dim3(grid_for(total)), dim3(256), 0, s, frames, crops, (bf16*)xs, N, T, H, W, Ts, Hs,
+              Ws, tstep, a[0], a[1], a[2], b[0], b[1], b[2]);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_ncs_to_nsc(const void* in, int in_is_bf16, void* out, int N, int C, long S, hipStream_t s) {

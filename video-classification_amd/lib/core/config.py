@@ -43,6 +43,11 @@ config.MODEL.PRETRAINED_PATH = 'pretrained_models/?'
 config.MODEL.CLIP_LEN = 16
 config.MODEL.CROP_SIZE = 112
 config.MODEL.DTYPE = 'bf16'
+# raw-frame input (uint8 N x Ts x Hs x Ws x 3 from a decoder): sampling / normalisation done on the GPU by
+# utils.ChooseInput -> vc_clip_pack_u8; mean / std in units of u8 / 255
+config.MODEL.FRAME_STEP = 1
+config.MODEL.MEAN = [0.43216, 0.394666, 0.37645]
+config.MODEL.STD = [0.22803, 0.22145, 0.216989]
 
 # training
 config.TRAIN = AttrDict()

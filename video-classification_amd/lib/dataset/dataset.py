@@ -17,6 +17,22 @@ class SyntheticClips(Dataset):
         return torch.randn(self.shape, generator=g), int(torch.randint(0, self.classes, (1,), generator=g))
 
 
+class SyntheticFrames(Dataset):
+    """raw decoded videos: uint8 Ts x Hs x Ws x 3 frames (what a decoder hands over), sampled / cropped / normalised
+    on the GPU by utils.ChooseInput (vc_clip_pack_u8) instead of by loader workers."""
+
+    def __init__(self, length, frames=32, height=128, width=171, classes=100, seed=1234):
+        self.length, self.shape, self.classes, self.seed = length, (frames, height, width, 3), classes, seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        return (torch.randint(0, 256, self.shape, generator=g, dtype=torch.uint8),
+                int(torch.randint(0, self.classes, (1,), generator=g)))
+
+
 def get_dataset(if_train=True, config=None, length=None):
     from core.config import config as default_config
     cfg = config or default_config

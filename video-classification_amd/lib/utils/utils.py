@@ -46,8 +46,30 @@ class AverageMeter(object):
 
 def ChooseInput(vedio, action):
     """reference utils.py:57-64 is an empty stub (frame/modality picking of the unfinished RL
-    design).  Here the whole clip is the model input whatever the action."""
-    return vedio
+    design).  Here the whole clip is the model input whatever the action.
+    Raw decoded frames (uint8 N x Ts x Hs x Ws x 3 on the GPU) are turned into the model's input here, in one
+    GPU pass (vc_clip_pack_u8): CLIP_LEN frames every FRAME_STEP, a CROP_SIZE crop, normalised with MODEL.MEAN/STD;
+    random position and horizontal flip while gradients are on (training), centred otherwise."""
+    if vedio.dtype != torch.uint8:
+        return vedio
+    from core.config import config as cfg
+    from vc3d import ops
+    if vedio.dim() != 5 or vedio.shape[-1] != 3:
+        raise ValueError("raw frames must be uint8 N x Ts x Hs x Ws x 3, got %s" % (tuple(vedio.shape),))
+    N, Ts, Hs, Ws, _ = vedio.shape
+    T, S, step = cfg.MODEL.CLIP_LEN, cfg.MODEL.CROP_SIZE, cfg.MODEL.FRAME_STEP
+    span = (T - 1) * step + 1
+    if Ts < span or Hs < S or Ws < S:
+        raise ValueError("frames %dx%dx%d are smaller than the clip %dx%dx%d (step %d)" % (Ts, Hs, Ws, T, S, S, step))
+    crops = torch.empty(N, 4, dtype=torch.int32)
+    if torch.is_grad_enabled():
+        crops[:, 0] = torch.randint(0, Ts - span + 1, (N,))
+        crops[:, 1] = torch.randint(0, Hs - S + 1, (N,))
+        crops[:, 2] = torch.randint(0, Ws - S + 1, (N,))
+        crops[:, 3] = torch.randint(0, 2, (N,))
+    else:
+        crops[:, 0], crops[:, 1], crops[:, 2], crops[:, 3] = (Ts - span) // 2, (Hs - S) // 2, (Ws - S) // 2, 0
+    return ops.clip_pack_u8(vedio.contiguous(), crops, T, S, S, step, cfg.MODEL.MEAN, cfg.MODEL.STD)
 
 
 def rollout(vedio, model, action, value):

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "vc_pack_dgrad_batched": [_P, _P, _P, _P, _I, _P],
     "vc_stem_packed_input_elems": [_I, _I, _I, _I],
     "vc_stem_pack_input": [_P, _I, _P, _I, _I, _I, _I, _P],
+    "vc_clip_pack_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P],
     "vc_stem_pack_weight": [_P, _P, _I, _P],
     "vc_stem_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vc_stem_fwd_bn": [_P, _P, _P, _P, _BF, _I, _I, _I, _I, _I, _P],

@@ -300,13 +300,15 @@ class R3DEngine:
 
     def forward(self, x, training, save):
         """x: [N][3][T][H][W] fp32/bf16 on the GPU.  Returns (features fp32 [N][F], saved state)."""
+        packed = isinstance(x, ops.PackedClips)  # from ops.clip_pack_u8: already the stem's packed source
         if x.dim() != 5 or x.shape[1] != 3:
             raise Vc3dError("expected a clip batch N x 3 x T x H x W, got %s" % (tuple(x.shape),))
         if not x.is_cuda:
             raise Vc3dError("the vc3d backbone runs on the GPU only (no CPU fallback); move the clips to cuda")
-        if x.dtype not in (F32, BF16):
-            x = x.float()
-        x = x.contiguous()
+        if not packed:
+            if x.dtype not in (F32, BF16):
+                x = x.float()
+            x = x.contiguous()
         N, _, T, H, W = x.shape
         dev = x.device
         self._nbt = []
@@ -316,7 +318,7 @@ class R3DEngine:
         if self.stem_wver != (w._version, self.param_epoch) or self.stem_ws is None or self.stem_ws.device != dev:
             self.stem_ws = ops.stem_pack_weight(w)
             self.stem_wver = (w._version, self.param_epoch)
-        xs = ops.stem_pack_input(x)
+        xs = x.xs if packed else ops.stem_pack_input(x)
         stats0 = stats_pool.take(st.Co) if training else None
         fin0, p0 = self._bn_fin(st, N * T * (H // 2) * (W // 2)) if training else (None, None)
         y0 = ops.stem_fwd(xs, self.stem_ws, N, T, H, W, st.Co, stats=stats0, fin=fin0)

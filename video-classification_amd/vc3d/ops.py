@@ -231,6 +231,39 @@ def stem_pack_input(x):
     return xs
 
 
+class PackedClips:
+    """a clip batch already in the stem's packed space-to-depth form (what stem_pack_input makes): the engine takes
+    it in place of the N x 3 x T x H x W tensor and skips its own packing pass."""
+
+    def __init__(self, xs, N, T, H, W):
+        self.xs, self.N, self.T, self.H, self.W = xs, N, T, H, W
+        self.shape = (N, 3, T, H, W)
+        self.device = xs.device
+        self.is_cuda = xs.is_cuda
+        self.requires_grad = False
+
+    def dim(self):
+        return 5
+
+
+def clip_pack_u8(frames, crops, T, H, W, tstep=1, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)):
+    """frames: uint8 [N][Ts][Hs][Ws][3] on the GPU; crops: int32 [N][4] = (t0, y0, x0, flip) on the HOST.
+    Temporal sampling + crop + flip + normalisation + bf16 + stem packing in one pass -> PackedClips."""
+    if frames.dim() != 5 or frames.shape[-1] != 3:
+        raise capi.Vc3dError("clip_pack_u8: expected uint8 frames N x Ts x Hs x Ws x 3, got %s" % (tuple(frames.shape),))
+    _chk(frames, torch.uint8, name="frames")
+    N, Ts, Hs, Ws, _ = frames.shape
+    if crops.is_cuda or crops.dtype != torch.int32 or tuple(crops.shape) != (N, 4) or not crops.is_contiguous():
+        raise capi.Vc3dError("clip_pack_u8: crops must be a contiguous int32 host tensor of shape N x 4")
+    crops_dev = crops.to(frames.device, non_blocking=True)
+    xs = torch.empty(N, T + 6, H // 2 + 3, stem_wp(W), 12, dtype=BF16, device=frames.device)
+    m = (capi.C.c_float * 3)(*[float(v) for v in mean])
+    s = (capi.C.c_float * 3)(*[float(v) for v in std])
+    check(lib.vc_clip_pack_u8(ptr(frames), ptr(crops_dev), crops.data_ptr(), ptr(xs), N, T, H, W, Ts, Hs, Ws, int(tstep),
+                              m, s, cur_stream()), "vc_clip_pack_u8")
+    return PackedClips(xs, N, T, H, W)
+
+
 def stem_pack_weight(w_master):
     Co = w_master.shape[0]
     if tuple(w_master.shape[1:]) != (3, 7, 7, 7):
