@@ -227,20 +227,24 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 }
 
 // dw += sum over slabs (deterministic split-K reduction of the weight gradient)
-// 64 float4 positions x 4 slab phases per block: phase q sums slabs q, q+4, ... (independent loads in flight),
-// the four partial sums are combined through LDS in a fixed order (deterministic)
+// (256 / PH) float4 positions x PH slab phases per block: phase q sums slabs q, q + PH, ... (independent loads in
+// flight), the PH partial sums are combined through LDS in a fixed order (deterministic).  PH = 16 for the many-slab
+// case (a 1x1x1 conv's 256 x 64 gradient comes as 512 slabs: with 4 phases a thread walked 128 of them in a
+// dependent chain, 19 us for 64 KB of output), PH = 4 otherwise.
+template <int PH>
 __global__ __launch_bounds__(256) void splitk_reduce_wgrad_kernel(const float* __restrict__ slabs, int splits,
                                                                   long long stride, float* __restrict__ dw, long n4) {
-    __shared__ f32x4 part[3][64];
-    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const long i = (long)blockIdx.x * 64 + l;
+    constexpr int NP = 256 / PH;
+    __shared__ f32x4 part[PH - 1][NP];
+    const int q = threadIdx.x / NP, l = threadIdx.x % NP;
+    const long i = (long)blockIdx.x * NP + l;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i < n4) {
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
         int z = q;
-        for (; z + 4 < splits; z += 8) {
+        for (; z + PH < splits; z += 2 * PH) {
             s += ((const f32x4*)(slabs + (size_t)z * stride))[i];
-            s1 += ((const f32x4*)(slabs + (size_t)(z + 4) * stride))[i];
+            s1 += ((const f32x4*)(slabs + (size_t)(z + PH) * stride))[i];
         }
         if (z < splits) s += ((const f32x4*)(slabs + (size_t)z * stride))[i];
         s += s1;
@@ -248,9 +252,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_wgrad_kernel(const float* _
     if (q > 0) part[q - 1][l] = s;
     __syncthreads();
     if (q == 0 && i < n4) {
-        s += part[0][l];
-        s += part[1][l];
-        s += part[2][l];
+#pragma unroll
+        for (int k = 0; k < PH - 1; ++k) s += part[k][l];
         f32x4 o = ((const f32x4*)dw)[i];
         o += s;
         ((f32x4*)dw)[i] = o;
@@ -1037,7 +1040,12 @@ int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, hipStream_t s) {
-    VC_LAUNCH(splitk_reduce_wgrad_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, slabs, splits, stride, dw, n / 4);
+    if (splits >= 32)
+        VC_LAUNCH((splitk_reduce_wgrad_kernel<16>), dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, s, slabs, splits,
+                  stride, dw, n / 4);
+    else
+        VC_LAUNCH((splitk_reduce_wgrad_kernel<4>), dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, slabs, splits,
+                  stride, dw, n / 4);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_bwd_finalize(const float* sums, int C, float count, float* coef, float* dgamma, float* dbeta,
