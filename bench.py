@@ -91,14 +91,16 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def pmc_traffic(op):
+def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes
     (profiles/pmc_traffic.json, made by scripts/pmc_check.sh + pmc_summary.py; bench.py cannot run the
-    profiler on itself).  None when that kernel has no measurement on file."""
+    profiler on itself).  None when that launch (kernel AND geometry) has no measurement on file."""
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(op)
-        return None if rec is None else rec["hbm_bytes"]
+            rec = json.load(f).get(key[0])
+        if rec is None or rec.get("launch") != "x".join(str(v) for v in key[1:]):
+            return None
+        return rec["hbm_bytes"]
     except (OSError, ValueError, KeyError):
         return None
 
@@ -209,7 +211,7 @@ def main():
             n, ms, fl = summ[dominant]
             ach = fl / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dominant[0]),
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dominant),
                     "kernel": "conv3d %s %s" % (dominant[0], "x".join(str(v) for v in dominant[1:])),
                     "launches_timed": n, "avg_ms": round(ms, 4), "flops_per_launch": fl}
 

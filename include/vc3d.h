@@ -63,9 +63,10 @@ int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y
                   size_t ws_bytes, void* stream);
 /* BatchNorm finalize folded into the launch that produces the sums (reference backbone.py:39-42,114: the
  * BatchNorm that follows every conv).  The workgroup that finishes last does vc_bn_finalize's work -- same
- * arithmetic, one launch less per layer.  `ticket`: one uint32 in device memory, zero before its first use; the
- * launch leaves it zero, so a zero-initialised word per layer is reused step after step.  Launches that share a
- * ticket word must not overlap.  `count` = elements per channel (N*T*H*W of y). */
+ * arithmetic, one launch less per layer.  `ticket`: VC_TICKET_WORDS (64) uint32 words in device memory, zero before their
+ * first use; the launch leaves them zero, so one zero-initialised block per layer is reused step after step.
+ * Launches that share a ticket block must not overlap.  `count` = elements per channel (N*T*H*W of y). */
+#define VC_TICKET_WORDS 64
 typedef struct vc_bn_fin {
     uint32_t* ticket;
     const float* gamma;

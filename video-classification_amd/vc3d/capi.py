@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC3D_LIB") or os.path.join(_HERE, "libvc3d.so")  # VC3D_LIB: experiment builds
 
 VC_STAT_REPLICAS = 32
+VC_TICKET_WORDS = 64  # int32 words behind a ticket pointer (bn_fin.h)
 STEM_K = 1344
 
 

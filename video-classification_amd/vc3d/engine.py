@@ -13,7 +13,7 @@ views of it with the parameter's own strides.
 import torch
 
 from . import ops
-from .capi import VC_STAT_REPLICAS, Vc3dError
+from .capi import VC_STAT_REPLICAS, VC_TICKET_WORDS, Vc3dError
 
 import os
 
@@ -243,13 +243,13 @@ class R3DEngine:
 
     # ------------------------------------------------------------------ forward
     def _ticket(self, cb, bwd):
-        """one zero int32 word per BatchNorm layer and direction (the fused finalize leaves it zero)."""
+        """one block of zero int32 ticket words per BatchNorm layer and direction (the fused finalize leaves it zero)."""
         dev = cb.bn.weight.device
         if self._tickets is None or self._tickets.device != dev:
             self._ticket_ix = {id(c): i for i, c in enumerate(self.all_convbn())}
-            self._tickets = torch.zeros(2 * len(self._ticket_ix), dtype=torch.int32, device=dev)
-        i = 2 * self._ticket_ix[id(cb)] + (1 if bwd else 0)
-        return self._tickets[i:i + 1]
+            self._tickets = torch.zeros(2 * len(self._ticket_ix) * VC_TICKET_WORDS, dtype=torch.int32, device=dev)
+        i = (2 * self._ticket_ix[id(cb)] + (1 if bwd else 0)) * VC_TICKET_WORDS
+        return self._tickets[i:i + VC_TICKET_WORDS]
 
     def _bticket(self, cb):
         return self._ticket(cb, True) if FUSED_BN_FIN else None

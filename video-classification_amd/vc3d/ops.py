@@ -110,10 +110,10 @@ def pack_weight(w_master, want_dgrad=True):
 
 def bn_fin(ticket, count, gamma, beta, running_mean, running_var, momentum, eps, params=None):
     """descriptor of a BatchNorm finalize folded into the conv launch that produces the sums (the last workgroup
-    does bn_finalize's work).  `ticket`: one int32 element, zero before its first use (left zero by the launch).
+    does bn_finalize's work).  `ticket`: capi.VC_TICKET_WORDS int32 words, zero before their first use (left zero by the launch).
     Returns (descriptor, params [4][C])."""
     Cn = gamma.numel()
-    _chk(ticket, torch.int32, 1, "ticket")
+    _chk(ticket, torch.int32, capi.VC_TICKET_WORDS, "ticket")
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
         _chk(t, F32, Cn, nm)
     if params is None:
@@ -366,7 +366,7 @@ def bn_apply(y, params, C, residual=None, relu=True, out=None):
 def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=False, sums=None, coef=None,
            dy=None, g_out=None, ticket=None):
     """BatchNorm backward (batch statistics).  Returns (dy, g) with g = masked dz or None.
-    `ticket` (one zero int32 element): the reduction's last workgroup does the finalize (one launch less)."""
+    `ticket` (capi.VC_TICKET_WORDS zero int32 words): the reduction's last workgroup does the finalize (one launch less)."""
     n = y.numel()
     _chk(y, BF16, name="y")
     _chk(dz, BF16, n, "dz")
@@ -389,7 +389,7 @@ def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=Fal
     _chk(g_out, BF16, n, "g_out")
     s = cur_stream()
     if ticket is not None:
-        _chk(ticket, torch.int32, 1, "ticket")
+        _chk(ticket, torch.int32, capi.VC_TICKET_WORDS, "ticket")
         check(lib.vc_bn_bwd_reduce_fin(ptr(y), ptr(dz), ptr(aux), ptr(params), ptr(sums), rows, C, mask, ptr(ticket),
                                        ptr(coef), ptr(gamma_grad), ptr(beta_grad), s), "vc_bn_bwd_reduce_fin")
     else:
@@ -424,7 +424,7 @@ def bn_bwd_pooled(pd, y, dpooled, idx, params, C, gamma_grad, beta_grad, sums=No
     dy = torch.empty_like(y)
     s = cur_stream()
     if ticket is not None:
-        _chk(ticket, torch.int32, 1, "ticket")
+        _chk(ticket, torch.int32, capi.VC_TICKET_WORDS, "ticket")
         check(lib.vc_bn_bwd_reduce_pooled_fin(pd, ptr(y), ptr(dpooled), ptr(idx), ptr(pooled), ptr(params), ptr(sums),
                                               ptr(ticket), ptr(coef), ptr(gamma_grad), ptr(beta_grad), s),
               "vc_bn_bwd_reduce_pooled_fin")
