@@ -19,6 +19,16 @@ rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
 prm = ops.bn_finalize(stats, y.numel() // C, gamma, beta, rm, rv, 0.1, 1e-5)
 pd = ops.pool_desc(N, C, T, H, W)
 pooled, idx = ops.maxpool3d_fwd(pd, y, prm)
+for _ in range(3):
+    ops.maxpool3d_fwd(pd, y, prm)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    ops.maxpool3d_fwd(pd, y, prm)
+e1.record()
+torch.cuda.synchronize()
+print("maxpool fwd (BN+ReLU fused): %.1f us (VC_POOL_NO_XCD=%s)" % (e0.elapsed_time(e1) * 1000 / 20, os.environ.get("VC_POOL_NO_XCD")))
 dp = torch.randn_like(pooled)
 dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
 for use_pooled in (False, True):
