@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--crop", type=int, default=112)
     ap.add_argument("--classes", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=0, help="timed oracle steps of the cpu_baseline leg (0: as many as fit ~12 s)")
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--eval", action="store_true", help="forward-only (valid.py path) throughput")
     return ap.parse_args()
@@ -72,11 +72,15 @@ def cpu_baseline(steps):
 
     step()  # warm-up
     t0 = time.time()
+    step()
+    if steps <= 0:  # a bounded sample: about 12 s of CPU work
+        steps = max(2, min(200, int(12.0 / max(time.time() - t0, 1e-3))))
+    t0 = time.time()
     for _ in range(steps):
         step()
     dt = (time.time() - t0) / steps
     return {"value": 8.0 / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d timed steps (1 warm-up) of oracle R3D-18 fp32 fwd+bwd+SGD on 8x3x16x112x112, %s" %
+            "sample": "%d timed steps (2 warm-up) of oracle R3D-18 fp32 fwd+bwd+SGD on 8x3x16x112x112, %s" %
                       (steps, _cpu_model())}
 
 

@@ -368,6 +368,39 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16x8* __restri
         for (int a = 0; a < g.kt; ++a) {
             const int t = to * g.st - g.pt + a;
             if ((unsigned)t >= (unsigned)g.T) continue;
+            if (g.kh == 3 && g.kw == 3) {
+                // the nine loads of a plane go out together (clamped addresses, validity applied at the compare):
+                // one load per tap behind its own bounds branch left a thread waiting out 27 memory latencies in a row
+                bf16x8 v9[9];
+                const int h0 = ho * g.sh - g.ph, w0 = wo * g.sw - g.pw;
+                const long plane = ((long)n * g.T + t) * g.H;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const int h = min(max(h0 + j / 3, 0), g.H - 1), w = min(max(w0 + j % 3, 0), g.W - 1);
+                    v9[j] = y[((plane + h) * g.W + w) * groups + cg];
+                }
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const bool ok = (unsigned)(h0 + j / 3) < (unsigned)g.H && (unsigned)(w0 + j % 3) < (unsigned)g.W;
+                    float f[8];
+                    unpack8(v9[j], f);
+                    const int tap = a * 9 + j;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float v = f[k];
+                        if (BN) {
+                            v = v * sc[k] + sh[k];
+                            v = v > 0.f ? v : 0.f;
+                            v = bf2f(f2bf(v));
+                        }
+                        if (ok && v > best[k]) {
+                            best[k] = v;
+                            bi[k] = tap;
+                        }
+                    }
+                }
+                continue;
+            }
             for (int b = 0; b < g.kh; ++b) {
                 const int h = ho * g.sh - g.ph + b;
                 if ((unsigned)h >= (unsigned)g.H) continue;
