@@ -83,18 +83,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16x8* __restrict_
 // MODE 1: BN backward sums: sum g, sum g*xhat with g = dz * mask
 //   MASK 0 none, 1 mask = (aux > 0) with aux the saved post-activation output,
 //        2 mask = (y*scale+shift > 0) recomputed
-// Rows are split over blocks; a block reduces its partial sums through LDS and adds them to
-// one of VC_STAT_REPLICAS copies of sums[2][C].
+// A block owns a 64-channel slice (8 lanes x 16 bytes = one 128-byte piece of every row it visits) and every RS-th
+// group of 32 rows; it reduces its partial sums through LDS and adds them to one of VC_STAT_REPLICAS copies of
+// sums[2][C].  The number of float atomics of a launch is RS x 2C whatever the channel split, so wide layers get
+// their parallelism from channel slices (C / 64 of them) and a small RS: with whole rows per block the 2-3 million
+// device-scope atomics of a C >= 512 layer took 90-120 us for a few MB of input (R3D-50 layer3/4).
 template <int MODE, int MASK>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restrict__ y, const bf16x8* __restrict__ dz,
                                                           const bf16x8* __restrict__ aux,
                                                           const float* __restrict__ params, float* sums, long rows,
-                                                          int C, int rows_per_block, VcBnFin ffin, VcBnBwdFin bfin) {
+                                                          int C, int CS, VcBnFin ffin, VcBnBwdFin bfin) {
     __shared__ float sm[256 * 17];
-    const int groups = C >> 3;             // 8-channel groups per row (<= 256)
-    const int rl = 256 / groups;           // row lanes per block
-    const int g = threadIdx.x % groups;
-    const int r = threadIdx.x / groups;
+    const int groups = C >> 3;             // 8-channel groups per row
+    const int cs = blockIdx.x % CS;        // channel slice: groups [8cs, 8cs + 8)
+    const int rs = blockIdx.x / CS;        // row phase
+    const int RS = gridDim.x / CS;
+    const int g = cs * 8 + (threadIdx.x & 7);
+    const int r = threadIdx.x >> 3;        // row lane 0..31
     float a0[8], a1[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
@@ -108,50 +113,44 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restri
             shift[k] = params[3 * C + g * 8 + k];
         }
     }
-    const long row0 = (long)blockIdx.x * rows_per_block;
-    long row1 = row0 + rows_per_block;
-    if (row1 > rows) row1 = rows;
-    if (r < rl) {
-        for (long row = row0 + r; row < row1; row += rl) {
-            const long i = row * groups + g;
-            float f[8];
-            unpack8(y[i], f);
-            if (MODE == 0) {
+    for (long row = (long)rs * 32 + r; row < rows; row += (long)RS * 32) {
+        const long i = row * groups + g;
+        float f[8];
+        unpack8(y[i], f);
+        if (MODE == 0) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    a0[k] += f[k];
-                    a1[k] += f[k] * f[k];
-                }
-            } else {
-                float d[8], m[8];
-                unpack8(dz[i], d);
-                if (MASK == 1) unpack8(aux[i], m);
+            for (int k = 0; k < 8; ++k) {
+                a0[k] += f[k];
+                a1[k] += f[k] * f[k];
+            }
+        } else {
+            float d[8], m[8];
+            unpack8(dz[i], d);
+            if (MASK == 1) unpack8(aux[i], m);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float gk = d[k];
-                    if (MASK == 1) gk = m[k] > 0.f ? gk : 0.f;
-                    if (MASK == 2) gk = (f[k] * scale[k] + shift[k]) > 0.f ? gk : 0.f;
-                    a0[k] += gk;
-                    a1[k] += gk * (f[k] - mean[k]) * invstd[k];
-                }
+            for (int k = 0; k < 8; ++k) {
+                float gk = d[k];
+                if (MASK == 1) gk = m[k] > 0.f ? gk : 0.f;
+                if (MASK == 2) gk = (f[k] * scale[k] + shift[k]) > 0.f ? gk : 0.f;
+                a0[k] += gk;
+                a1[k] += gk * (f[k] - mean[k]) * invstd[k];
             }
         }
     }
-    // block reduce over row lanes
+    // block reduce over the 32 row lanes: thread (k, gg) sums value k of channel group gg
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         sm[threadIdx.x * 17 + k] = a0[k];
         sm[threadIdx.x * 17 + 8 + k] = a1[k];
     }
     __syncthreads();
-    if (threadIdx.x < groups) {
-        float* dst = sums + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * C;
-        for (int k = 0; k < 16; ++k) {
-            float s = 0.f;
-            for (int rr = 0; rr < rl; ++rr) s += sm[(rr * groups + threadIdx.x) * 17 + k];
-            const int c = threadIdx.x * 8 + (k & 7);
-            atomicAdd(dst + (k < 8 ? 0 : C) + c, s);
-        }
+    if (threadIdx.x < 128) {
+        const int gg = threadIdx.x & 7, k = threadIdx.x >> 3;
+        float s = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < 32; ++rr) s += sm[(rr * 8 + gg) * 17 + k];
+        float* dst = sums + (size_t)(rs & (VC_STAT_REPLICAS - 1)) * 2 * C;
+        atomicAdd(dst + (k < 8 ? 0 : C) + (cs * 8 + gg) * 8 + (k & 7), s);
     }
     if (MODE == 0) vc_bn_fin_last(ffin, sums, C);
     else vc_bn_bwd_fin_last(bfin, sums, C);
@@ -1035,9 +1034,20 @@ static void reduce_geometry(long rows, int C, int& grid, int& rpb) {
     grid = (int)((rows + rpb - 1) / rpb);
 }
 
+// chan_reduce_kernel: CS = C / 64 channel slices x RS row phases; RS keeps the launch near 2048 blocks, its float
+// atomics (RS x 2C) at 256k or fewer, and at least two 32-row groups per block
+static void chan_reduce_geometry(long rows, int C, int& grid, int& CS) {
+    CS = C / 64;
+    long RS = 2048 / CS;
+    if (RS > 131072 / C) RS = 131072 / C;
+    const long by_rows = (rows + 63) / 64;
+    if (RS > by_rows) RS = by_rows;
+    if (RS < 1) RS = 1;
+    grid = (int)(RS * CS);
+}
 int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, const VcBnFin* fin, hipStream_t s) {
     int grid, rpb;
-    reduce_geometry(rows, C, grid, rpb);
+    chan_reduce_geometry(rows, C, grid, rpb);
     VC_LAUNCH((chan_reduce_kernel<0, 0>), dim3(grid), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)nullptr,
                        (const bf16x8*)nullptr, (const float*)nullptr, sums, rows, C, rpb, fin ? *fin : VcBnFin{},
                        VcBnBwdFin{});
@@ -1046,7 +1056,7 @@ int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, const VcBnFin* 
 int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums, long rows,
                         int C, int mask, const VcBnBwdFin* fin, hipStream_t s) {
     int grid, rpb;
-    reduce_geometry(rows, C, grid, rpb);
+    chan_reduce_geometry(rows, C, grid, rpb);
     const bf16x8 *yy = (const bf16x8*)y, *dd = (const bf16x8*)dz, *aa = (const bf16x8*)aux;
     const VcBnBwdFin bf = fin ? *fin : VcBnBwdFin{};
     if (mask == 0)
