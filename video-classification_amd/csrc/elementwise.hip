@@ -163,46 +163,42 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ slabs, int splits,
                                                               long long stride, bf16x8* __restrict__ out,
                                                               int accumulate, float* stats, long rows, int C,
-                                                              int rows_per_block, VcBnFin fin) {
+                                                              int CS, VcBnFin fin) {
+    // same decomposition as chan_reduce_kernel: 64-channel slice x row phase (float atomics per launch = RS x 2C)
     __shared__ float sm[STATS ? 256 * 17 : 1];
     const int groups = C >> 3;
-    const int rl = 256 / groups;
-    const int g = threadIdx.x % groups;
-    const int r = threadIdx.x / groups;
+    const int cs = blockIdx.x % CS, rs = blockIdx.x / CS, RS = gridDim.x / CS;
+    const int g = cs * 8 + (threadIdx.x & 7);
+    const int r = threadIdx.x >> 3;
     float a0[8], a1[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
-    const long row0 = (long)blockIdx.x * rows_per_block;
-    long row1 = row0 + rows_per_block;
-    if (row1 > rows) row1 = rows;
-    if (r < rl) {
-        for (long row = row0 + r; row < row1; row += rl) {
-            const long i = row * groups + g;
-            float v[8];
+    for (long row = (long)rs * 32 + r; row < rows; row += (long)RS * 32) {
+        const long i = row * groups + g;
+        float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = 0.f;
-            for (int z = 0; z < splits; ++z) {
-                const f32x4* src = (const f32x4*)(slabs + (size_t)z * stride + i * 8);
-                const f32x4 lo = src[0], hi = src[1];
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        for (int z = 0; z < splits; ++z) {
+            const f32x4* src = (const f32x4*)(slabs + (size_t)z * stride + i * 8);
+            const f32x4 lo = src[0], hi = src[1];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[k] += lo[k];
-                    v[4 + k] += hi[k];
-                }
+            for (int k = 0; k < 4; ++k) {
+                v[k] += lo[k];
+                v[4 + k] += hi[k];
             }
-            if (accumulate) {
-                float o[8];
-                unpack8(out[i], o);
+        }
+        if (accumulate) {
+            float o[8];
+            unpack8(out[i], o);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += o[k];
-            }
-            out[i] = pack8(v);
-            if (STATS) {
+            for (int k = 0; k < 8; ++k) v[k] += o[k];
+        }
+        out[i] = pack8(v);
+        if (STATS) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    a0[k] += v[k];
-                    a1[k] += v[k] * v[k];
-                }
+            for (int k = 0; k < 8; ++k) {
+                a0[k] += v[k];
+                a1[k] += v[k] * v[k];
             }
         }
     }
@@ -213,13 +209,13 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
             sm[threadIdx.x * 17 + 8 + k] = a1[k];
         }
         __syncthreads();
-        if (threadIdx.x < groups) {
-            float* dst = stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * C;
-            for (int k = 0; k < 16; ++k) {
-                float s = 0.f;
-                for (int rr = 0; rr < rl; ++rr) s += sm[(rr * groups + threadIdx.x) * 17 + k];
-                atomicAdd(dst + (k < 8 ? 0 : C) + threadIdx.x * 8 + (k & 7), s);
-            }
+        if (threadIdx.x < 128) {
+            const int gg = threadIdx.x & 7, k = threadIdx.x >> 3;
+            float s = 0.f;
+#pragma unroll 8
+            for (int rr = 0; rr < 32; ++rr) s += sm[(rr * 8 + gg) * 17 + k];
+            float* dst = stats + (size_t)(rs & (VC_STAT_REPLICAS - 1)) * 2 * C;
+            atomicAdd(dst + (k < 8 ? 0 : C) + (cs * 8 + gg) * 8 + (k & 7), s);
         }
         vc_bn_fin_last(fin, stats, C);
     }
@@ -1025,15 +1021,6 @@ int vc_ew_bn_apply(const void* y, const float* params, const void* res, void* ou
     return VC_CHECK_LAUNCH();
 }
 
-static void reduce_geometry(long rows, int C, int& grid, int& rpb) {
-    const int rl = 256 / (C / 8);
-    long want = (rows + (long)rl * 2 - 1) / ((long)rl * 2);  // >= 2 rows per thread, at most 2048 blocks
-    if (want > 2048) want = 2048;
-    if (want < 1) want = 1;
-    rpb = (int)((rows + want - 1) / want);
-    grid = (int)((rows + rpb - 1) / rpb);
-}
-
 // chan_reduce_kernel: CS = C / 64 channel slices x RS row phases; RS keeps the launch near 2048 blocks, its float
 // atomics (RS x 2C) at 256k or fewer, and at least two 32-row groups per block
 static void chan_reduce_geometry(long rows, int C, int& grid, int& CS) {
@@ -1073,7 +1060,7 @@ int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const fl
 int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void* out, int accumulate, float* stats,
                           long rows, int C, const VcBnFin* fin, hipStream_t s) {
     int grid, rpb;
-    reduce_geometry(rows, C, grid, rpb);
+    chan_reduce_geometry(rows, C, grid, rpb);
     if (stats)
         VC_LAUNCH((splitk_finalize_kernel<true>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
                   accumulate, stats, rows, C, rpb, fin ? *fin : VcBnFin{});

@@ -306,7 +306,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
     }
 
     if (p.stats != nullptr && p.partial == nullptr) {
-        float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
+        // lanes -> wave (shuffles) -> workgroup (LDS: the waves that share a co range) -> one float atomic per channel
+        // and moment per workgroup.  (Device-scope float atomics cost ~40 ps each chip-wide: 512 per workgroup, as
+        // one set per wave made, were 18 us of a 65 us pointwise conv.)
+        float* sred = (float*)smem;  // [WM][2][BCO]; the staged tile was read out before the loop's last barrier
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -318,10 +321,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
                     qq += __shfl_xor(qq, o);
                 }
                 if (l15 == 0) {
-                    atomicAdd(srep + cobase + a * 16 + j, ss);
-                    atomicAdd(srep + p.Cn + cobase + a * 16 + j, qq);
+                    sred[(wm * 2 + 0) * BCO + wco * 64 + a * 16 + lg * 4 + j] = ss;
+                    sred[(wm * 2 + 1) * BCO + wco * 64 + a * 16 + lg * 4 + j] = qq;
                 }
             }
+        }
+        __syncthreads();
+        float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
+        for (int i = tid; i < 2 * BCO; i += 256) {
+            const int mom = i / BCO, c = i - mom * BCO;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < Cfg::WM; ++w) v += sred[(w * 2 + mom) * BCO + c];
+            atomicAdd(srep + mom * p.Cn + co0 + c, v);
         }
     }
     if (p.partial == nullptr) vc_bn_fin_last(p.fin, p.stats, p.Cn);
