@@ -701,8 +701,17 @@ __global__ void linear_bwd_data_kernel(const float* __restrict__ dlog, const flo
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * F) return;
     const int n = i / F, f = i - n * F;
+    // eight loads in flight, summed in k order (the plain loop waited out one memory latency per k: 95 us for K = 400)
     float s = 0.f;
-    for (int k = 0; k < K; ++k) s += dlog[(size_t)n * K + k] * W[(size_t)k * F + f];
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+        float w[8], d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = W[(size_t)(k + u) * F + f], d[u] = dlog[(size_t)n * K + k + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += d[u] * w[u];
+    }
+    for (; k < K; ++k) s += dlog[(size_t)n * K + k] * W[(size_t)k * F + f];
     dfeat[i] = s;
 }
 // dW[k][f] += sum_n dlog[n][k] feat[n][f] ; db[k] += sum_n dlog[n][k]
@@ -712,7 +721,15 @@ __global__ void linear_bwd_weight_kernel(const float* __restrict__ dlog, const f
     if (i >= K * F) return;
     const int k = i / F, f = i - k * F;
     float s = 0.f, sb = 0.f;
-    for (int n = 0; n < N; ++n) {
+    int n = 0;
+    for (; n + 8 <= N; n += 8) {
+        float x[8], d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = feat[(size_t)(n + u) * F + f], d[u] = dlog[(size_t)(n + u) * K + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += d[u] * x[u], sb += d[u];
+    }
+    for (; n < N; ++n) {
         const float d = dlog[(size_t)n * K + k];
         s += d * feat[(size_t)n * F + f];
         sb += d;
