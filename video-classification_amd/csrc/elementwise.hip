@@ -759,16 +759,22 @@ __global__ __launch_bounds__(256) void stem_pack_input_kernel(const TIN* __restr
         const int t = tp - 3, h2 = hp - 2, w2 = wp - 2;
         bf16 v[12];
         const bool in = (unsigned)t < (unsigned)T && (unsigned)h2 < (unsigned)(H / 2) && (unsigned)w2 < (unsigned)(W / 2);
+        // the two pixels (bw = 0, 1) of a source row are adjacent and pair-aligned (W is even): one load for both
+        struct alignas(2 * sizeof(TIN)) Pair {
+            TIN a, b;
+        };
 #pragma unroll
         for (int bh = 0; bh < 2; ++bh)
 #pragma unroll
-            for (int bw = 0; bw < 2; ++bw)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float f = 0.f;
-                    if (in) f = (float)x[((((long)n * 3 + c) * T + t) * H + (2 * h2 + bh)) * W + (2 * w2 + bw)];
-                    v[(bh * 2 + bw) * 3 + c] = f2bf(f);
+            for (int c = 0; c < 3; ++c) {
+                float f0 = 0.f, f1 = 0.f;
+                if (in) {
+                    const Pair pr = *(const Pair*)(x + ((((long)n * 3 + c) * T + t) * H + (2 * h2 + bh)) * W + 2 * w2);
+                    f0 = (float)pr.a, f1 = (float)pr.b;
                 }
+                v[(bh * 2 + 0) * 3 + c] = f2bf(f0);
+                v[(bh * 2 + 1) * 3 + c] = f2bf(f1);
+            }
         bf16x4* dst = (bf16x4*)(xs + i * 12);
         dst[0] = (bf16x4){v[0], v[1], v[2], v[3]};
         dst[1] = (bf16x4){v[4], v[5], v[6], v[7]};
