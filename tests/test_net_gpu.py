@@ -156,3 +156,32 @@ def test_packed_uint8_clips_give_the_float_path_logits():
         _, lo_f, _ = prod(x.cuda())
     torch.cuda.synchronize()
     assert rel_l2(lo_u8, lo_f) <= 2e-3
+
+
+def test_full_bench_size_batch_split_property():
+    """BASELINE config 2's full size (64 x 3 x 16 x 112 x 112, R3D-18, 101 classes), where the CPU oracle is too slow to
+    be the checker: size-independent properties instead.  Eval mode (running statistics, so samples do not interact):
+    the logits of the batch of 64 equal those of its two halves run separately (tilings, split-K plans and
+    persistent-grid shapes all differ between M = 64 and M = 32 clips; bar: rel-L2 <= 2e-3, same top-1).  Train mode:
+    one step at the full batch gives a finite loss near ln(101) (within 0.05 ln(101) + 0.5: random initialisation)
+    and finite gradients in every parameter."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    import math
+    _, prod, _ = build_pair(18, 101, device="cuda:0")
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(64, 3, 16, 112, 112, generator=g).to(torch.bfloat16).cuda()
+    y = torch.randint(0, 101, (64,), generator=g).cuda()
+    prod.eval()
+    with torch.no_grad():
+        full = prod(x)[1].float()
+        halves = torch.cat([prod(x[:32])[1], prod(x[32:])[1]]).float()
+    torch.cuda.synchronize()
+    assert rel_l2(full, halves) <= 2e-3
+    assert bool((full.argmax(1) == halves.argmax(1)).all())
+    prod.train()
+    loss = F.cross_entropy(prod(x)[1], y)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert math.isfinite(float(loss)) and abs(float(loss) - math.log(101)) <= 0.05 * math.log(101) + 0.5
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in prod.parameters())
