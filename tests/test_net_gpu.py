@@ -185,3 +185,30 @@ def test_full_bench_size_batch_split_property():
     torch.cuda.synchronize()
     assert math.isfinite(float(loss)) and abs(float(loss) - math.log(101)) <= 0.05 * math.log(101) + 0.5
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in prod.parameters())
+
+
+def test_fused_and_separate_batchnorm_finalize_agree():
+    """the engine's default (BatchNorm finalize done by the last workgroup of the producing launch) against separate
+    finalize launches (VC_NO_BN_FIN): same arithmetic on sums that differ only by the arrival order of float atomics,
+    so logits, running statistics and gradients agree to fp32 round-off amplified through the net (bar 2e-3)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    from vc3d import engine as eng_mod
+    from oracle.r3d_torch import synthetic_batch
+    x, y = synthetic_batch(2, 8, 64, 64, 7, 3)
+    out = {}
+    keep = eng_mod.FUSED_BN_FIN
+    try:
+        for fused in (True, False):
+            eng_mod.FUSED_BN_FIN = fused
+            _, prod, _ = build_pair(18, 7, device="cuda:0")
+            prod.train()
+            lo = prod(x.cuda())[1]
+            F.cross_entropy(lo, y.cuda()).backward()
+            torch.cuda.synchronize()
+            out[fused] = (lo.detach().float().cpu(), prod.backbone.bn1.running_var.detach().cpu().clone(),
+                          torch.cat([p.grad.detach().float().flatten().cpu() for p in prod.parameters()]))
+    finally:
+        eng_mod.FUSED_BN_FIN = keep
+    for a, b in zip(out[True], out[False]):
+        assert rel_l2(a, b) <= 2e-3
