@@ -30,6 +30,7 @@ def main():
     geom = [int(v) for v in a[:9]]
     forces = [None]
     ops_sel = "fwd,dgrad,wgrad"
+    no_stats = False
     i = 9
     while i < len(a):
         if a[i] == "--force":
@@ -38,6 +39,9 @@ def main():
         elif a[i] == "--ops":
             ops_sel = a[i + 1]
             i += 2
+        elif a[i] == "--no-stats":
+            no_stats = True
+            i += 1
         else:
             raise SystemExit("bad arg " + a[i])
     N, Ci, T, H, W, Co, k, s, p = geom
@@ -48,7 +52,7 @@ def main():
     w = (torch.randn(Co, Ci, k, k, k, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last_3d)
     wf, wd = ops.pack_weight(w)
     dw = torch.zeros(Co, k, k, k, Ci, device="cuda")
-    stats = ops.new_stats(Co, x.device)
+    stats = None if no_stats else ops.new_stats(Co, x.device)
     flops = 2.0 * N * To * Ho * Wo * Co * Ci * k ** 3
     y = torch.empty(N, To, Ho, Wo, Co, device="cuda", dtype=torch.bfloat16)
     dx = torch.empty_like(x)
