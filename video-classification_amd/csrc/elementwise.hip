@@ -1056,40 +1056,40 @@ static void chan_reduce_geometry(long rows, int C, int& grid, int& CS) {
     grid = (int)(RS * CS);
 }
 int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, const VcBnFin* fin, hipStream_t s) {
-    int grid, rpb;
-    chan_reduce_geometry(rows, C, grid, rpb);
+    int grid, slices;
+    chan_reduce_geometry(rows, C, grid, slices);
     VC_LAUNCH((chan_reduce_kernel<0, 0>), dim3(grid), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)nullptr,
-                       (const bf16x8*)nullptr, (const float*)nullptr, sums, rows, C, rpb, fin ? *fin : VcBnFin{},
+                       (const bf16x8*)nullptr, (const float*)nullptr, sums, rows, C, slices, fin ? *fin : VcBnFin{},
                        VcBnBwdFin{});
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums, long rows,
                         int C, int mask, const VcBnBwdFin* fin, hipStream_t s) {
-    int grid, rpb;
-    chan_reduce_geometry(rows, C, grid, rpb);
+    int grid, slices;
+    chan_reduce_geometry(rows, C, grid, slices);
     const bf16x8 *yy = (const bf16x8*)y, *dd = (const bf16x8*)dz, *aa = (const bf16x8*)aux;
     const VcBnBwdFin bf = fin ? *fin : VcBnBwdFin{};
     if (mask == 0)
-        VC_LAUNCH((chan_reduce_kernel<1, 0>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb,
+        VC_LAUNCH((chan_reduce_kernel<1, 0>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
                   VcBnFin{}, bf);
     else if (mask == 1)
-        VC_LAUNCH((chan_reduce_kernel<1, 1>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb,
+        VC_LAUNCH((chan_reduce_kernel<1, 1>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
                   VcBnFin{}, bf);
     else
-        VC_LAUNCH((chan_reduce_kernel<1, 2>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, rpb,
+        VC_LAUNCH((chan_reduce_kernel<1, 2>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
                   VcBnFin{}, bf);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void* out, int accumulate, float* stats,
                           long rows, int C, const VcBnFin* fin, hipStream_t s) {
-    int grid, rpb;
-    chan_reduce_geometry(rows, C, grid, rpb);
+    int grid, slices;
+    chan_reduce_geometry(rows, C, grid, slices);
     if (stats)
         VC_LAUNCH((splitk_finalize_kernel<true>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
-                  accumulate, stats, rows, C, rpb, fin ? *fin : VcBnFin{});
+                  accumulate, stats, rows, C, slices, fin ? *fin : VcBnFin{});
     else
         VC_LAUNCH((splitk_finalize_kernel<false>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
-                  accumulate, stats, rows, C, rpb, VcBnFin{});
+                  accumulate, stats, rows, C, slices, VcBnFin{});
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, hipStream_t s) {
