@@ -31,19 +31,24 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #ifndef VC_STEMF_ABLATE
 #define VC_STEMF_ABLATE 0  // timing experiments only: 1 = weight tiles not refilled, 2 = image planes not refilled
 #endif
-constexpr int NWAVE = 7;
+#ifndef VC_STEMF_NT
+#define VC_STEMF_NT 2  // 16-position tiles per wave and frame: 2 -> 7 waves of 32 positions, 4 -> 4 waves of 64
+#endif
+constexpr int NT = VC_STEMF_NT;
+constexpr int PW = NT * 16;          // positions per wave and frame
+constexpr int NWAVE = NT == 2 ? 7 : 4;
 constexpr int WPITCH = 416;          // bytes per weight row in LDS: 384 data + 32 pad (conflict-free ds_read_b128)
 constexpr int WPIECES = 26;          // 64 rows x 26 slots of 16 bytes = 26 pieces of 1 KiB
 constexpr int WBUF = WPIECES * 1024;
 constexpr int NSLOT = 8;             // plane ring: the 8 planes of a frame pair; the next pair's two new planes
                                      // replace planes t, t+1 once temporal tap 1 is done with them
 constexpr int NWB = 3;               // weight tiles in flight: tap g is computed while g+1 and g+2 stream in
-constexpr int WPW = 4;               // weight DMA instructions per wave and tile (26 pieces + 2 dummies over 7 waves)
+constexpr int WPW = (WPIECES + NWAVE - 1) / NWAVE;  // weight DMA instructions per wave and tile (26 pieces + dummies)
 constexpr int W_OFF = 0;
 constexpr int DUMMY_OFF = NWB * WBUF;  // 1 KiB that the dummy DMA instructions land in
 constexpr int PL_OFF = NWB * WBUF + 1024;
 
-__global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem_fwd_kernel(
+__global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NT == 2 ? 2 : 1, 2))) void stem_fwd_kernel(
     const VcStemFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -56,10 +61,10 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2
     const gptr_t zero = (gptr_t)vc_stemf_zero_page;
 
     // this lane's two positions (B columns) of the chunk, and the k offsets of its 8-element group per k-step
-    int mloc[2], posoff[2];
+    int mloc[NT], posoff[NT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        mloc[nt] = wave * 32 + nt * 16 + l15;
+    for (int nt = 0; nt < NT; ++nt) {
+        mloc[nt] = wave * PW + nt * 16 + l15;
         const int hl = mloc[nt] / p.Wo;
         const int w = mloc[nt] - hl * p.Wo;
         posoff[nt] = mloc[nt] < CP ? hl * RP + w * 24 : 0;
@@ -121,19 +126,20 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2
         if (nsteps > 1) issue_w(1, 1);
         int g = 0;  // step counter of the unit: weight tile of step g sits in buffer g % NWB
         for (int t = t0; t < t1; t += 2) {
-            f32x4 acc[4][2][2];
+            f32x4 acc[4][2][NT];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int f = 0; f < 2; ++f)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) acc[a][f][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int nt = 0; nt < NT; ++nt) acc[a][f][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int kt = 0; kt < 7; ++kt, ++g) {
                 // tile g has landed once at most the younger tile g+1 is in flight; the step after the plane
                 // refill (kt == 3) and the unit's last step drain everything
+                static_assert(WPW == 4 || WPW == 7, "counted wait below");
                 if (kt == 3 || g + 1 >= nsteps) __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-                else __builtin_amdgcn_s_waitcnt(0x0074);                             // vmcnt(4) lgkmcnt(0)
+                else __builtin_amdgcn_s_waitcnt(WPW == 4 ? 0x0074 : 0x0077);         // vmcnt(WPW) lgkmcnt(0)
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 const int wbuf = g % NWB;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                     for (int f = 0; f < 2; ++f)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
+                        for (int nt = 0; nt < NT; ++nt) {
                             const char* bp = (f ? pl1 : pl0) + posoff[nt] + koff[ks];
                             const bf16x4 lo = *(const bf16x4*)bp;
                             const bf16x4 hi = *(const bf16x4*)(bp + 8);
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2
                 if (t + f >= t1) continue;
                 const long mrow = ((long)(n * p.T + t + f) * p.Ho + h0) * p.Wo;
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     if (mloc[nt] >= cpv) continue;
                     bf16* dst = p.y + (mrow + mloc[nt]) * 64 + lg * 4;
 #pragma unroll
@@ -234,12 +240,12 @@ int vc_stem_fwd_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcSte
     const int RP = Wp * 24;
     int best_rh = 0;
     double best_eff = 0.0;
-    for (int RH = 1; RH <= Ho && RH * Wo <= NWAVE * 32; ++RH) {
+    for (int RH = 1; RH <= Ho && RH * Wo <= NWAVE * PW; ++RH) {
         const int pieces = ((RH + 3) * RP + 1023) / 1024;
         const long lds = (long)NWB * WBUF + 1024 + (long)NSLOT * pieces * 1024;
         if (lds > 160 * 1024) break;
         const int nhg = (Ho + RH - 1) / RH;
-        const double eff = ((double)Ho * Wo / ((double)nhg * NWAVE * 32)) * ((double)RH / (RH + 1.0));
+        const double eff = ((double)Ho * Wo / ((double)nhg * NWAVE * PW)) * ((double)RH / (RH + 1.0));
         if (eff > best_eff) best_eff = eff, best_rh = RH;
     }
     if (best_rh == 0) return 0;
