@@ -477,3 +477,32 @@ def test_clip_pack_u8_rejects_bad_tables():
         ops.clip_pack_u8(frames.cpu(), ok, 4, 16, 16, 2)
     with pytest.raises(Vc3dError):
         ops.clip_pack_u8(frames, ok, 4, 16, 16, 2, std=(1.0, 0.0, 1.0))
+
+
+@pytest.mark.parametrize("case", [(2, 64, 4, 12, 12, 64, 3, 1, 1), (2, 64, 4, 8, 8, 128, 1, 1, 0), (2, 128, 4, 8, 8, 128, 3, 2, 1),
+                                  (8, 256, 2, 7, 7, 256, 3, 1, 1)])
+def test_conv3d_fwd_inference_epilogue(case):
+    """vc_conv3d_fwd_act: y = relu(scale * conv(x) + shift) in the conv epilogue == conv then vc_bn_apply, up to the one
+    bf16 rounding the fused form saves (bar: 1.5 bf16 ulp of the larger operand per element; vs fp32 torch TOL_BF16).
+    Covers the halo kernel, the implicit GEMM (1x1x1 and strided) and a split-K geometry (applied after its finalize)."""
+    _need_gpu()
+    from vc3d import ops
+    N, Ci, T, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = bf16_round(torch.randn(N, Ci, T, H, W, generator=g))
+    w = bf16_round(torch.randn(Co, Ci, k, k, k, generator=g) * (2.0 / (Ci * k ** 3)) ** 0.5)
+    gamma, beta = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.2
+    rm, rv = torch.randn(Co, generator=g) * 0.1, torch.rand(Co, generator=g) + 0.5
+    ref = torch.relu(F.batch_norm(F.conv3d(x, w, stride=s, padding=p), rm, rv, gamma, beta, False, 0.0, 1e-5))
+    d = ops.conv_desc(N, Ci, T, H, W, Co, k, s, p)
+    wf, _ = ops.pack_weight(cl3d_param(w))
+    xd = to_nthwc_dev(x)
+    prm = ops.bn_eval_params(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-5)
+    z_fused = ops.conv3d_fwd(d, xd, wf, act_params=prm, relu=True)
+    z_two = ops.bn_apply(ops.conv3d_fwd(d, xd, wf), prm, Co, relu=True)
+    torch.cuda.synchronize()
+    assert rel_l2(from_nthwc(z_fused), ref) <= TOL_BF16
+    a, b = z_fused.float().cpu(), z_two.float().cpu()
+    assert rel_l2(a, b) <= TOL_BF16
+    with pytest.raises(Exception):
+        ops.conv3d_fwd(d, xd, wf, stats=ops.new_stats(Co, "cuda"), act_params=prm)

@@ -58,7 +58,7 @@ static int conv_check(const vc_conv3d_desc* d, int& To, int& Ho, int& Wo) {
 }
 
 static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const void* w, void* out, float* stats,
-                    const VcBnFin* fin,
+                    const VcBnFin* fin, const float* ep_params, int ep_relu,
                     int accumulate, void* workspace, size_t ws_bytes, void* stream);
 
 extern "C" {
@@ -219,12 +219,13 @@ size_t vc_conv3d_workspace_bytes(const vc_conv3d_desc* d, int32_t op) {
 }
 
 static int conv3d_fwd_impl(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats,
-                           const VcBnFin* fin, void* workspace, size_t ws_bytes, void* stream) {
+                           const VcBnFin* fin, const float* ep_params, int ep_relu, void* workspace, size_t ws_bytes,
+                           void* stream) {
     int To, Ho, Wo;
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(x && w && y, "conv3d_fwd: null pointer");
-    if (halo_ok(d)) return halo_run(d, false, x, w, y, bn_stats, fin, 0, workspace, ws_bytes, stream);
+    if (halo_ok(d)) return halo_run(d, false, x, w, y, bn_stats, fin, ep_params, ep_relu, 0, workspace, ws_bytes, stream);
     VcIgemmParams p;
     memset(&p, 0, sizeof(p));
     p.src = (const bf16*)x;
@@ -261,9 +262,12 @@ static int conv3d_fwd_impl(const vc_conv3d_desc* d, const void* x, const void* w
         p.stats = nullptr;
         rc = vc_launch_igemm(p, 0, S(stream));
         if (rc) return rc;
-        return vc_ew_splitk_finalize(p.partial, splits, p.partial_stride, y, 0, bn_stats, p.M, d->Co, fin, S(stream));
+        rc = vc_ew_splitk_finalize(p.partial, splits, p.partial_stride, y, 0, bn_stats, p.M, d->Co, fin, S(stream));
+        if (rc || ep_params == nullptr) return rc;
+        return vc_ew_bn_apply(y, ep_params, nullptr, y, (long)out_e, d->Co, ep_relu, S(stream));  // in place
     }
     if (fin != nullptr && bn_stats != nullptr) p.fin = *fin;
+    p.ep_params = ep_params, p.ep_relu = ep_relu;
     return vc_launch_igemm(p, 0, S(stream));
 }
 
@@ -280,20 +284,25 @@ static int make_fin(const vc_bn_fin* f, const float* stats, VcBnFin& o) {
 
 int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, void* workspace,
                   size_t ws_bytes, void* stream) {
-    return conv3d_fwd_impl(d, x, w, y, bn_stats, nullptr, workspace, ws_bytes, stream);
+    return conv3d_fwd_impl(d, x, w, y, bn_stats, nullptr, nullptr, 0, workspace, ws_bytes, stream);
+}
+int vc_conv3d_fwd_act(const vc_conv3d_desc* d, const void* x, const void* w, void* y, const float* bn_params,
+                      int32_t relu, void* workspace, size_t ws_bytes, void* stream) {
+    VC_REQUIRE(bn_params != nullptr, "conv3d_fwd_act: bn_params is required");
+    return conv3d_fwd_impl(d, x, w, y, nullptr, nullptr, bn_params, relu ? 1 : 0, workspace, ws_bytes, stream);
 }
 int vc_conv3d_fwd_bn(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, const vc_bn_fin* fin,
                      void* workspace, size_t ws_bytes, void* stream) {
     VcBnFin f;
     int rc = make_fin(fin, bn_stats, f);
     if (rc) return rc;
-    return conv3d_fwd_impl(d, x, w, y, bn_stats, &f, workspace, ws_bytes, stream);
+    return conv3d_fwd_impl(d, x, w, y, bn_stats, &f, nullptr, 0, workspace, ws_bytes, stream);
 }
 
 }  // extern "C"
 
 static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const void* w, void* out, float* stats,
-                    const VcBnFin* fin,
+                    const VcBnFin* fin, const float* ep_params, int ep_relu,
                     int accumulate, void* workspace, size_t ws_bytes, void* stream) {
     VcHaloPlan plan;
     if (halo_plan(d, dgrad, &plan)) {
@@ -316,9 +325,12 @@ static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const 
         p.stats = nullptr;
         int rc = vc_launch_halo(p, plan, S(stream));
         if (rc) return rc;
-        return vc_ew_splitk_finalize(p.partial, plan.splits, p.partial_stride, out, accumulate, stats,
-                                     (long)(out_e / p.Cn), p.Cn, stats ? fin : nullptr, S(stream));
+        rc = vc_ew_splitk_finalize(p.partial, plan.splits, p.partial_stride, out, accumulate, stats,
+                                   (long)(out_e / p.Cn), p.Cn, stats ? fin : nullptr, S(stream));
+        if (rc || ep_params == nullptr) return rc;
+        return vc_ew_bn_apply(out, ep_params, nullptr, out, (long)out_e, p.Cn, ep_relu, S(stream));  // in place
     }
+    p.ep_params = ep_params, p.ep_relu = ep_relu;
     // The halo kernel runs several rounds of one workgroup per CU: a ticket round trip at the end of every workgroup
     // costs more there than the separate finalize launch (measured), so the finalize stays a launch of its own.
     int rc = vc_launch_halo(p, plan, S(stream));
@@ -338,7 +350,7 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(dy && w_dgrad && dx, "conv3d_dgrad: null pointer");
-    if (halo_ok(d)) return halo_run(d, true, dy, w_dgrad, dx, nullptr, nullptr, accumulate, workspace, ws_bytes, stream);
+    if (halo_ok(d)) return halo_run(d, true, dy, w_dgrad, dx, nullptr, nullptr, nullptr, 0, accumulate, workspace, ws_bytes, stream);
     const int ntaps_all = d->kt * d->kh * d->kw;
     const size_t dx_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
     int splits = dgrad_splits(d);

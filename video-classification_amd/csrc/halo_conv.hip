@@ -393,6 +393,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         return;
     }
+    if (p.ep_params != nullptr) {
+        // inference: BatchNorm with fixed (running) statistics is a per-channel scale and shift, applied with the
+        // ReLU on the fp32 accumulators, so the conv output is rounded to bf16 once and no separate pass reads it back
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 s4 = *(const f32x4*)(p.ep_params + 2 * p.Cn + cobase + a * 16);
+            const f32x4 h4 = *(const f32x4*)(p.ep_params + 3 * p.Cn + cobase + a * 16);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[a][b][j] * s4[j] + h4[j];
+                    if (p.ep_relu) v = v > 0.f ? v : 0.f;
+                    acc[a][b][j] = v;
+                }
+        }
+    }
     __syncthreads();  // every wave has left the tap loop: the image area is free
     // The image area is reused: [NW][64 positions][64 co] bf16 with a 144-byte row pitch for the output
     // tile (so that it leaves as whole 128-byte channels-last rows, 16 bytes per lane), then

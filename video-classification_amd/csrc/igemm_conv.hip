@@ -247,6 +247,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
             continue;
         }
 
+        if (p.ep_params != nullptr) {
+            // inference: BatchNorm with fixed (running) statistics is a per-channel scale and shift, applied with the
+            // ReLU on the fp32 accumulators, so the conv output is rounded to bf16 once and no separate pass reads it back
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 s4 = *(const f32x4*)(p.ep_params + 2 * p.Cn + cobase + a * 16);
+                const f32x4 h4 = *(const f32x4*)(p.ep_params + 3 * p.Cn + cobase + a * 16);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[a][b][j] * s4[j] + h4[j];
+                        if (p.ep_relu) v = v > 0.f ? v : 0.f;
+                        acc[a][b][j] = v;
+                    }
+            }
+        }
         if (p.stats != nullptr) {  // rows beyond M hold exact zeros
 #pragma unroll
             for (int a = 0; a < 4; ++a)

@@ -9,6 +9,8 @@ struct VcIgemmParams {
     bf16* out;
     float* stats;  // nullable: [VC_STAT_REPLICAS][2][Cn]
     VcBnFin fin;   // fin.ticket nullable: the last workgroup finalizes the BatchNorm parameters (bn_fin.h)
+    const float* ep_params;  // nullable: BatchNorm params [4][Cn] applied in the epilogue (out = scale * acc + shift)
+    int ep_relu;             // ... followed by ReLU
     int M, Ta, Ha, Wa;
     VcFastDiv dWa, dHa, dTa;
     int Ts, Hs, Ws, Cs;
@@ -56,6 +58,8 @@ struct VcHaloParams {
     bf16* out;        // [NP*H*W][Cn]
     float* stats;     // nullable: [VC_STAT_REPLICAS][2][Cn]
     VcBnFin fin;      // fin.ticket nullable: the last workgroup finalizes the BatchNorm parameters (bn_fin.h)
+    const float* ep_params;  // nullable: BatchNorm params [4][Cn] applied in the epilogue (out = scale * acc + shift)
+    int ep_relu;             // ... followed by ReLU
     int NP, T, H, W;  // NP = N*T planes of H*W rows
     int Cs, Cn, Kw, ntaps;
     int TT, SEG, HR, halo_rows, npieces, ntg, nseg;  // filled by vc_launch_halo from the plan

@@ -19,6 +19,7 @@ import os
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+FUSED_EVAL_ACT = os.environ.get("VC_NO_EVAL_ACT") is None  # inference: BatchNorm + ReLU in the conv epilogue
 FUSED_BN_FIN = os.environ.get("VC_NO_BN_FIN") is None  # BatchNorm finalize done by the last workgroup of the producer
 SIDE_WGRAD = os.environ.get("VC_WGRAD_SIDE_STREAM", "1") != "0"  # weight gradients on a side stream (engine._wgrad)
 
@@ -337,8 +338,13 @@ class R3DEngine:
             recs = []
             h = xin
             for i, cb in enumerate(cbs):
-                d, y, prm = self._conv_bn(cb, h, training, stats_pool)
                 last = (i == len(cbs) - 1)
+                if not last and not training and not save and self.trace is None and FUSED_EVAL_ACT:
+                    # inference: BatchNorm (running statistics) + ReLU applied in the conv's epilogue
+                    wf, _ = cb.weights()
+                    h = ops.conv3d_fwd(cb.desc(h), h, wf, act_params=self._bn_params(cb, None, 0, False), relu=True)
+                    continue
+                d, y, prm = self._conv_bn(cb, h, training, stats_pool)
                 if not last:
                     z = ops.bn_apply(y, prm, cb.Co, relu=True)
                     recs.append((d, h, y, prm, z))

@@ -125,7 +125,9 @@ def bn_fin(ticket, count, gamma, beta, running_mean, running_var, momentum, eps,
     return f, params
 
 
-def conv3d_fwd(d, x, wf, stats=None, out=None, fin=None):
+def conv3d_fwd(d, x, wf, stats=None, out=None, fin=None, act_params=None, relu=True):
+    """act_params ([4][Co] BatchNorm params with fixed statistics, inference): y = relu(scale * conv + shift) in the
+    conv's own epilogue (no separate bn_apply pass); not combinable with stats / fin."""
     To, Ho, Wo = d.out_dims()
     taps = d.kt * d.kh * d.kw
     _chk(x, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "x")
@@ -136,7 +138,13 @@ def conv3d_fwd(d, x, wf, stats=None, out=None, fin=None):
     _chk(stats, F32, VC_STAT_REPLICAS * 2 * d.Co, "bn_stats")
     ev = TIMER.begin(_conv_key("fwd", d), _conv_flops(d)) if TIMER is not None else None
     ws, wsb = _workspace(d, 0, x.device)
-    if fin is not None:
+    if act_params is not None:
+        if stats is not None or fin is not None:
+            raise capi.Vc3dError("conv3d_fwd: act_params (inference) excludes batch statistics")
+        _chk(act_params, F32, 4 * d.Co, "bn params")
+        check(lib.vc_conv3d_fwd_act(d, ptr(x), ptr(wf), ptr(out), ptr(act_params), 1 if relu else 0, ws, wsb,
+                                    cur_stream()), "vc_conv3d_fwd_act")
+    elif fin is not None:
         check(lib.vc_conv3d_fwd_bn(d, ptr(x), ptr(wf), ptr(out), ptr(stats), fin, ws, wsb, cur_stream()),
               "vc_conv3d_fwd_bn")
     else:
