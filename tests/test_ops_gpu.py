@@ -506,3 +506,10 @@ def test_conv3d_fwd_inference_epilogue(case):
     assert rel_l2(a, b) <= TOL_BF16
     with pytest.raises(Exception):
         ops.conv3d_fwd(d, xd, wf, stats=ops.new_stats(Co, "cuda"), act_params=prm)
+    # residual form: relu(scale * conv + shift + res); in the implicit-GEMM epilogue for 1x1x1 / strided convs,
+    # conv + in-place vc_bn_apply behind a 3x3x3 halo conv or a split-K geometry
+    res = bf16_round(torch.randn(ref.shape, generator=g))
+    ref_r = torch.relu(F.batch_norm(F.conv3d(x, w, stride=s, padding=p), rm, rv, gamma, beta, False, 0.0, 1e-5) + res)
+    z_r = ops.conv3d_fwd(d, xd, wf, act_params=prm, relu=True, residual=to_nthwc_dev(res))
+    torch.cuda.synchronize()
+    assert rel_l2(from_nthwc(z_r), ref_r) <= TOL_BF16

@@ -219,13 +219,19 @@ size_t vc_conv3d_workspace_bytes(const vc_conv3d_desc* d, int32_t op) {
 }
 
 static int conv3d_fwd_impl(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats,
-                           const VcBnFin* fin, const float* ep_params, int ep_relu, void* workspace, size_t ws_bytes,
-                           void* stream) {
+                           const VcBnFin* fin, const float* ep_params, int ep_relu, const void* ep_res, void* workspace,
+                           size_t ws_bytes, void* stream) {
     int To, Ho, Wo;
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(x && w && y, "conv3d_fwd: null pointer");
-    if (halo_ok(d)) return halo_run(d, false, x, w, y, bn_stats, fin, ep_params, ep_relu, 0, workspace, ws_bytes, stream);
+    if (halo_ok(d)) {
+        if (ep_res == nullptr) return halo_run(d, false, x, w, y, bn_stats, fin, ep_params, ep_relu, 0, workspace, ws_bytes, stream);
+        // residual form behind a halo conv: the add stays in vc_bn_apply (in place)
+        rc = halo_run(d, false, x, w, y, nullptr, nullptr, nullptr, 0, 0, workspace, ws_bytes, stream);
+        if (rc) return rc;
+        return vc_ew_bn_apply(y, ep_params, ep_res, y, (long)d->N * To * Ho * Wo * d->Co, d->Co, ep_relu, S(stream));
+    }
     VcIgemmParams p;
     memset(&p, 0, sizeof(p));
     p.src = (const bf16*)x;
@@ -264,10 +270,10 @@ static int conv3d_fwd_impl(const vc_conv3d_desc* d, const void* x, const void* w
         if (rc) return rc;
         rc = vc_ew_splitk_finalize(p.partial, splits, p.partial_stride, y, 0, bn_stats, p.M, d->Co, fin, S(stream));
         if (rc || ep_params == nullptr) return rc;
-        return vc_ew_bn_apply(y, ep_params, nullptr, y, (long)out_e, d->Co, ep_relu, S(stream));  // in place
+        return vc_ew_bn_apply(y, ep_params, ep_res, y, (long)out_e, d->Co, ep_relu, S(stream));  // in place
     }
     if (fin != nullptr && bn_stats != nullptr) p.fin = *fin;
-    p.ep_params = ep_params, p.ep_relu = ep_relu;
+    p.ep_params = ep_params, p.ep_relu = ep_relu, p.ep_res = (const bf16*)ep_res;
     return vc_launch_igemm(p, 0, S(stream));
 }
 
@@ -284,19 +290,20 @@ static int make_fin(const vc_bn_fin* f, const float* stats, VcBnFin& o) {
 
 int vc_conv3d_fwd(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, void* workspace,
                   size_t ws_bytes, void* stream) {
-    return conv3d_fwd_impl(d, x, w, y, bn_stats, nullptr, nullptr, 0, workspace, ws_bytes, stream);
+    return conv3d_fwd_impl(d, x, w, y, bn_stats, nullptr, nullptr, 0, nullptr, workspace, ws_bytes, stream);
 }
 int vc_conv3d_fwd_act(const vc_conv3d_desc* d, const void* x, const void* w, void* y, const float* bn_params,
-                      int32_t relu, void* workspace, size_t ws_bytes, void* stream) {
+                      const void* residual, int32_t relu, void* workspace, size_t ws_bytes, void* stream) {
     VC_REQUIRE(bn_params != nullptr, "conv3d_fwd_act: bn_params is required");
-    return conv3d_fwd_impl(d, x, w, y, nullptr, nullptr, bn_params, relu ? 1 : 0, workspace, ws_bytes, stream);
+    VC_REQUIRE(residual != y || residual == nullptr, "conv3d_fwd_act: the residual must not alias the output");
+    return conv3d_fwd_impl(d, x, w, y, nullptr, nullptr, bn_params, relu ? 1 : 0, residual, workspace, ws_bytes, stream);
 }
 int vc_conv3d_fwd_bn(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, const vc_bn_fin* fin,
                      void* workspace, size_t ws_bytes, void* stream) {
     VcBnFin f;
     int rc = make_fin(fin, bn_stats, f);
     if (rc) return rc;
-    return conv3d_fwd_impl(d, x, w, y, bn_stats, &f, nullptr, 0, workspace, ws_bytes, stream);
+    return conv3d_fwd_impl(d, x, w, y, bn_stats, &f, nullptr, 0, nullptr, workspace, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float v = acc[a][b][j] * s4[j] + h4[j];
-                        if (p.ep_relu) v = v > 0.f ? v : 0.f;
+                        if (p.ep_relu && p.ep_res == nullptr) v = v > 0.f ? v : 0.f;  // with a residual: after the add
                         acc[a][b][j] = v;
                     }
             }
@@ -288,11 +288,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
         int* sOut = (int*)(smem + BM * OPITCH);
         if (tid < BM) sOut[tid] = my_ooff;
         __syncthreads();
-        if (p.accumulate) {
+        const bf16* addsrc = p.ep_res != nullptr ? p.ep_res : (p.accumulate ? p.out : nullptr);  // what is added in
+        if (addsrc != nullptr) {
             for (int i = tid; i < BM * PPR; i += 256) {
                 const int r = i / PPR, c8 = i - r * PPR;
                 const int oo = sOut[r];
-                if (oo >= 0) *(bf16x8*)(smem + r * OPITCH + c8 * 16) = *(const bf16x8*)(p.out + (size_t)oo + co0 + c8 * 8);
+                if (oo >= 0) *(bf16x8*)(smem + r * OPITCH + c8 * 16) = *(const bf16x8*)(addsrc + (size_t)oo + co0 + c8 * 8);
             }
             __syncthreads();
         }
@@ -302,12 +303,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
             for (int a = 0; a < 4; ++a) {
                 bf16x4* q = (bf16x4*)(smem + (wm * 64 + b * 16 + l15) * OPITCH + (wco * 64 + a * 16 + lg * 4) * 2);
                 f32x4 v = acc[a][b];
-                if (p.accumulate) {
+                if (addsrc != nullptr) {
                     const bf16x4 old = *q;
                     v[0] += bf2f(old[0]);
                     v[1] += bf2f(old[1]);
                     v[2] += bf2f(old[2]);
                     v[3] += bf2f(old[3]);
+                    if (p.ep_res != nullptr && p.ep_relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    }
                 }
                 bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                 *q = o;

@@ -11,6 +11,7 @@ struct VcIgemmParams {
     VcBnFin fin;   // fin.ticket nullable: the last workgroup finalizes the BatchNorm parameters (bn_fin.h)
     const float* ep_params;  // nullable: BatchNorm params [4][Cn] applied in the epilogue (out = scale * acc + shift)
     int ep_relu;             // ... followed by ReLU
+    const bf16* ep_res;      // nullable (with ep_params): residual, laid out like out, added before the ReLU
     int M, Ta, Ha, Wa;
     VcFastDiv dWa, dHa, dTa;
     int Ts, Hs, Ws, Cs;

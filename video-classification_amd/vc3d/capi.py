@@ -68,7 +68,7 @@ PROTOTYPES = {
     "vc_conv3d_workspace_bytes": [_CD, _I],
     "vc_conv3d_fwd": [_CD, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "vc_conv3d_fwd_bn": [_CD, _P, _P, _P, _P, _BF, _P, C.c_size_t, _P],
-    "vc_conv3d_fwd_act": [_CD, _P, _P, _P, _P, _I, _P, C.c_size_t, _P],
+    "vc_conv3d_fwd_act": [_CD, _P, _P, _P, _P, _P, _I, _P, C.c_size_t, _P],
     "vc_conv3d_dgrad": [_CD, _P, _P, _P, _I, _P, C.c_size_t, _P],
     "vc_conv3d_wgrad": [_CD, _P, _P, _P, _P, C.c_size_t, _P],
     "vc_pack_weight": [_P, _P, _P, _I, _I, _I, _P],

@@ -333,17 +333,25 @@ class R3DEngine:
         if not save:
             del xs, y0, idx
         cur = a0
+        fused_eval = not training and not save and self.trace is None and FUSED_EVAL_ACT
         for cbs, ds in self.blocks:
             xin = cur
             recs = []
             h = xin
+            if fused_eval:
+                # inference: BatchNorm (running statistics), the residual add and the ReLU are applied in the conv's
+                # epilogue (vc_conv3d_fwd_act); no conv output is materialised before them
+                def act(cb, x, relu, residual=None):
+                    wf, _ = cb.weights()
+                    return ops.conv3d_fwd(cb.desc(x), x, wf, act_params=self._bn_params(cb, None, 0, False), relu=relu,
+                                          residual=residual)
+                for cb in cbs[:-1]:
+                    h = act(cb, h, True)
+                r = act(ds, xin, False) if ds is not None else xin
+                cur = act(cbs[-1], h, True, residual=r)
+                continue
             for i, cb in enumerate(cbs):
                 last = (i == len(cbs) - 1)
-                if not last and not training and not save and self.trace is None and FUSED_EVAL_ACT:
-                    # inference: BatchNorm (running statistics) + ReLU applied in the conv's epilogue
-                    wf, _ = cb.weights()
-                    h = ops.conv3d_fwd(cb.desc(h), h, wf, act_params=self._bn_params(cb, None, 0, False), relu=True)
-                    continue
                 d, y, prm = self._conv_bn(cb, h, training, stats_pool)
                 if not last:
                     z = ops.bn_apply(y, prm, cb.Co, relu=True)

@@ -125,7 +125,7 @@ def bn_fin(ticket, count, gamma, beta, running_mean, running_var, momentum, eps,
     return f, params
 
 
-def conv3d_fwd(d, x, wf, stats=None, out=None, fin=None, act_params=None, relu=True):
+def conv3d_fwd(d, x, wf, stats=None, out=None, fin=None, act_params=None, relu=True, residual=None):
     """act_params ([4][Co] BatchNorm params with fixed statistics, inference): y = relu(scale * conv + shift) in the
     conv's own epilogue (no separate bn_apply pass); not combinable with stats / fin."""
     To, Ho, Wo = d.out_dims()
@@ -142,7 +142,8 @@ def conv3d_fwd(d, x, wf, stats=None, out=None, fin=None, act_params=None, relu=T
         if stats is not None or fin is not None:
             raise capi.Vc3dError("conv3d_fwd: act_params (inference) excludes batch statistics")
         _chk(act_params, F32, 4 * d.Co, "bn params")
-        check(lib.vc_conv3d_fwd_act(d, ptr(x), ptr(wf), ptr(out), ptr(act_params), 1 if relu else 0, ws, wsb,
+        _chk(residual, BF16, out.numel(), "residual")
+        check(lib.vc_conv3d_fwd_act(d, ptr(x), ptr(wf), ptr(out), ptr(act_params), ptr(residual), 1 if relu else 0, ws, wsb,
                                     cur_stream()), "vc_conv3d_fwd_act")
     elif fin is not None:
         check(lib.vc_conv3d_fwd_bn(d, ptr(x), ptr(wf), ptr(out), ptr(stats), fin, ws, wsb, cur_stream()),
