@@ -82,8 +82,7 @@ int vc_conv3d_fwd_bn(const vc_conv3d_desc* d, const void* x, const void* w, void
  * a per-channel scale and shift, so it is applied with the ReLU in the conv's epilogue on the fp32 accumulators:
  * y = relu(scale * conv(x) + shift [+ residual]), bn_params = [4][Co] as vc_bn_eval_params writes them, residual
  * (nullable, laid out like y, not y itself) = the block input of `out += residual` (backbone.py:59-60,100-101).
- * No separate vc_bn_apply pass, one rounding to bf16.  (Split-K geometries, and the residual form behind a 3x3x3
- * conv, apply it in place after the conv.) */
+ * No separate vc_bn_apply pass.  (Split-K geometries apply it in place after the conv.) */
 int vc_conv3d_fwd_act(const vc_conv3d_desc* d, const void* x, const void* w, void* y, const float* bn_params,
                       const void* residual, int32_t relu, void* workspace, size_t ws_bytes, void* stream);
 int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx,

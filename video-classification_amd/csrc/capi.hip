@@ -58,7 +58,7 @@ static int conv_check(const vc_conv3d_desc* d, int& To, int& Ho, int& Wo) {
 }
 
 static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const void* w, void* out, float* stats,
-                    const VcBnFin* fin, const float* ep_params, int ep_relu,
+                    const VcBnFin* fin, const float* ep_params, int ep_relu, const void* ep_res,
                     int accumulate, void* workspace, size_t ws_bytes, void* stream);
 
 extern "C" {
@@ -225,13 +225,7 @@ static int conv3d_fwd_impl(const vc_conv3d_desc* d, const void* x, const void* w
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(x && w && y, "conv3d_fwd: null pointer");
-    if (halo_ok(d)) {
-        if (ep_res == nullptr) return halo_run(d, false, x, w, y, bn_stats, fin, ep_params, ep_relu, 0, workspace, ws_bytes, stream);
-        // residual form behind a halo conv: the add stays in vc_bn_apply (in place)
-        rc = halo_run(d, false, x, w, y, nullptr, nullptr, nullptr, 0, 0, workspace, ws_bytes, stream);
-        if (rc) return rc;
-        return vc_ew_bn_apply(y, ep_params, ep_res, y, (long)d->N * To * Ho * Wo * d->Co, d->Co, ep_relu, S(stream));
-    }
+    if (halo_ok(d)) return halo_run(d, false, x, w, y, bn_stats, fin, ep_params, ep_relu, ep_res, 0, workspace, ws_bytes, stream);
     VcIgemmParams p;
     memset(&p, 0, sizeof(p));
     p.src = (const bf16*)x;
@@ -309,7 +303,7 @@ int vc_conv3d_fwd_bn(const vc_conv3d_desc* d, const void* x, const void* w, void
 }  // extern "C"
 
 static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const void* w, void* out, float* stats,
-                    const VcBnFin* fin, const float* ep_params, int ep_relu,
+                    const VcBnFin* fin, const float* ep_params, int ep_relu, const void* ep_res,
                     int accumulate, void* workspace, size_t ws_bytes, void* stream) {
     VcHaloPlan plan;
     if (halo_plan(d, dgrad, &plan)) {
@@ -335,9 +329,9 @@ static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const 
         rc = vc_ew_splitk_finalize(p.partial, plan.splits, p.partial_stride, out, accumulate, stats,
                                    (long)(out_e / p.Cn), p.Cn, stats ? fin : nullptr, S(stream));
         if (rc || ep_params == nullptr) return rc;
-        return vc_ew_bn_apply(out, ep_params, nullptr, out, (long)out_e, p.Cn, ep_relu, S(stream));  // in place
+        return vc_ew_bn_apply(out, ep_params, ep_res, out, (long)out_e, p.Cn, ep_relu, S(stream));  // in place
     }
-    p.ep_params = ep_params, p.ep_relu = ep_relu;
+    p.ep_params = ep_params, p.ep_relu = ep_relu, p.ep_res = (const bf16*)ep_res;
     // The halo kernel runs several rounds of one workgroup per CU: a ticket round trip at the end of every workgroup
     // costs more there than the separate finalize launch (measured), so the finalize stays a launch of its own.
     int rc = vc_launch_halo(p, plan, S(stream));
@@ -357,7 +351,7 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(dy && w_dgrad && dx, "conv3d_dgrad: null pointer");
-    if (halo_ok(d)) return halo_run(d, true, dy, w_dgrad, dx, nullptr, nullptr, nullptr, 0, accumulate, workspace, ws_bytes, stream);
+    if (halo_ok(d)) return halo_run(d, true, dy, w_dgrad, dx, nullptr, nullptr, nullptr, 0, nullptr, accumulate, workspace, ws_bytes, stream);
     const int ntaps_all = d->kt * d->kh * d->kw;
     const size_t dx_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
     int splits = dgrad_splits(d);

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = acc[a][b][j] * s4[j] + h4[j];
-                    if (p.ep_relu) v = v > 0.f ? v : 0.f;
+                    if (p.ep_relu && p.ep_res == nullptr) v = v > 0.f ? v : 0.f;  // with a residual: after the add
                     acc[a][b][j] = v;
                 }
         }
@@ -466,7 +466,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const int r = i * 8 + (lane >> 3);
             const int oo = sooff[wave * 64 + r];
             if (oo >= 0) {
-                const bf16x8 v = *(const bf16x8*)(otile + r * OPITCH + (lane & 7) * 16);
+                bf16x8 v = *(const bf16x8*)(otile + r * OPITCH + (lane & 7) * 16);
+                if (p.ep_res != nullptr) {
+                    // residual add (+ ReLU) on the staged rows: whole 16-byte pieces of the residual, as the store
+                    // (the staged value is already bf16: two roundings, as conv -> bf16 -> bn_apply has)
+                    const bf16x8 rr = *(const bf16x8*)(p.ep_res + (size_t)oo + co0 + (lane & 7) * 8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float f = bf2f(v[k]) + bf2f(rr[k]);
+                        if (p.ep_relu) f = f > 0.f ? f : 0.f;
+                        v[k] = f2bf(f);
+                    }
+                }
                 *(bf16x8*)(p.out + (size_t)oo + co0 + (lane & 7) * 8) = v;
             }
         }

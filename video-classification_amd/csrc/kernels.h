@@ -61,6 +61,7 @@ struct VcHaloParams {
     VcBnFin fin;      // fin.ticket nullable: the last workgroup finalizes the BatchNorm parameters (bn_fin.h)
     const float* ep_params;  // nullable: BatchNorm params [4][Cn] applied in the epilogue (out = scale * acc + shift)
     int ep_relu;             // ... followed by ReLU
+    const bf16* ep_res;      // nullable (with ep_params, not with accumulate): residual laid out like out, added before the ReLU
     int NP, T, H, W;  // NP = N*T planes of H*W rows
     int Cs, Cn, Kw, ntaps;
     int TT, SEG, HR, halo_rows, npieces, ntg, nseg;  // filled by vc_launch_halo from the plan
