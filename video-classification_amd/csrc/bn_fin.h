@@ -77,12 +77,16 @@ __device__ __forceinline__ void vc_bn_bwd_finalize_channel(const float* sums, in
 
 // Called by EVERY thread of EVERY workgroup of the launch, after the workgroup's last statistics atomic.
 // True (in all threads) for the workgroup that arrived last.
-// No release fence here: on gfx950 a device-scope fence writes back the XCD's L2, which at this point holds the
-// workgroup's freshly written output tile (measured: 5.7 -> 9.8 ms per R3D-18 step).  Only the ORDER of atomics
-// matters: the statistics atomics and the ticket are device-scope read-modify-writes performed at the memory side,
-// a thread's atomics are acknowledged (vmcnt) once performed, and the ticket is drawn after every thread of the
-// workgroup has seen its acknowledgements (vmcnt(0), barrier).  The last workgroup reads the sums with device-scope
-// loads, which do not hit this XCD's L2.
+// Producer side: NO release fence.  On gfx950 a device-scope release writes back the XCD's L2, which at this point
+// holds the workgroup's freshly written output tile (measured: 5.7 -> 9.8 ms per R3D-18 step), and the bytes handed
+// over here need none: they are written by device-scope read-modify-write atomics only, which are performed at the
+// memory side (below every XCD's L2; MI355X_MICROARCH.md, rows 'atomics of each flavour' and 'Global float
+// atomics').  What the hand-off does need on this side is ORDER: every wave waits for the acknowledgements of its
+// own atomics (vmcnt(0)), the workgroup's barrier follows, and only then does one lane draw the ticket.
+// Consumer side: the workgroup that draws the last ticket runs an agent-scope ACQUIRE (buffer_inv sc1: drops this
+// CU's L1 lines; ~1.7 us, paid by one workgroup per launch) before any of its waves reads the sums -- a reader in
+// the adds' own launch needs it whatever the load flavour (same table, row 'read in the same launch') -- and the
+// reads are device-scope (sc1) loads on top, so they are served below this XCD's L2 as well.
 // Two levels of tickets: a reduction kernel's 2048 workgroups finish within a few microseconds of each other, and
 // 2048 returning atomics on ONE word serialise at the memory side (measured: +10 us on a 20 us kernel).  Workgroup b
 // draws from word 1 + (b & 31); the one that completes its word draws from word 0; the one that completes word 0
@@ -105,6 +109,8 @@ __device__ __forceinline__ bool vc_last_workgroup(unsigned* ticket) {
             if (t2 == groups - 1u) {
                 __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 last = 1u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate has completed before the barrier releases the readers
             }
         }
         s_last = last;

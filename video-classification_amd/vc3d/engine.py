@@ -83,6 +83,7 @@ class R3DEngine:
         self.flat_shadow = None  # bf16 copy of flat_param (conv slices = forward / wgrad operands)
         self.flat_wd = None      # bf16 dgrad operands of every conv, packed by one launch
         self.param_epoch = 0     # bumped by a fused optimizer step (memory changed behind torch's back)
+        self.stat_epoch = 0      # bumped by every training forward: running statistics are updated by raw pointer
         self.grad_views = None
         self.grad_ready_cb = None  # set by the data-parallel wrapper: cb(param)
         self._side = None          # side stream of the weight-gradient launches (see _wgrad)
@@ -280,7 +281,10 @@ class R3DEngine:
             if bn.track_running_stats and bn.num_batches_tracked is not None:
                 self._nbt.append(bn.num_batches_tracked)
             return p
-        ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version)
+        # gamma/beta are rewritten by the fused optimizer step and the running statistics by the finalize kernels, both
+        # through raw pointers (no tensor version moves): the two epoch counters stand for those writes
+        ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+               bn.weight.data_ptr(), bn.running_mean.data_ptr(), self.param_epoch, self.stat_epoch)
         if cb.eval_params is None or cb.eval_ver != ver or cb.eval_params.device != bn.weight.device:
             cb.eval_params = ops.bn_eval_params(bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                 bn.running_var, bn.eps)
@@ -313,6 +317,8 @@ class R3DEngine:
         N, _, T, H, W = x.shape
         dev = x.device
         self._nbt = []
+        if training:
+            self.stat_epoch += 1
         stats_pool = _StatsPool(sum(cb.Co for cb in self.all_convbn()), dev) if training else None
         st = self.stem
         w = st.conv.weight
