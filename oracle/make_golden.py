@@ -25,6 +25,9 @@ What it writes, and what pins what:
   r3d18_small.npz                 -- whole-net oracle R3D-18 on a seeded 4x3x8x64x64 batch (2 clips of 32x32 leave late BN layers with 2 values per channel: ill-conditioned):
       logits, loss, per-parameter gradient norms, BN running statistics after one step.
   r3d18_full.npz                  -- the same at the bench geometry, 2x3x16x112x112, 101 classes: logits, loss, gradient norms.
+  r3d50_full.npz / r3d50_long.npz -- R3D-50, 400 classes, at BASELINE config 3's geometry (2x3x16x112x112) and config 4's
+      (1x3x64x224x224): logits, loss, per-parameter gradient norms of the fp32 oracle, and the same from the oracle's
+      bf16-storage emulation (keys emu/...).
 
 Inputs and weights that are too large to commit are regenerated from seeds; a SHA-256 of
 their bytes is stored so a test can tell "RNG stream changed" from "arithmetic changed".
@@ -222,6 +225,45 @@ def r3d18_full():
     print("r3d18_full loss %.6f" % float(loss))
 
 
+def _whole_net(depth, classes, n, t, hw, seed, tag, emulate=True):
+    """fp32 oracle logits / loss / per-parameter gradient norms (+ two whole gradient tensors) and the same from the
+    oracle's bf16-storage emulation (the yardstick for what bf16 storage + bf16 MFMA operands cost at this size)."""
+    from oracle.r3d_torch import forward_emulated
+    rec = {}
+    for kind in (("fp32", "emu") if emulate else ("fp32",)):
+        model = init_weights_(R3DOracle(depth, classes), 0).train()
+        x, y = synthetic_batch(n, t, hw, hw, classes, seed)
+        if kind == "fp32":
+            rec["x_sha"] = np.array(sha(x))
+            rec["w_sha"] = np.array(hashlib.sha256(b"".join(p.detach().numpy().tobytes() for p in model.parameters())).hexdigest())
+            rec["y"] = y.numpy()
+        logits = model(x) if kind == "fp32" else forward_emulated(model, x)
+        loss = F.cross_entropy(logits, y)
+        loss.backward()
+        pre = "" if kind == "fp32" else "emu/"
+        rec[pre + "logits"] = logits.detach().numpy()
+        rec[pre + "loss"] = np.float64(float(loss))
+        for nme, p in model.named_parameters():
+            rec[pre + "gnorm/" + nme] = np.float64(float(p.grad.double().norm()))
+        for nme in ("clf_head.bias", "backbone.bn1.weight"):
+            rec[pre + "grad/" + nme] = dict(model.named_parameters())[nme].grad.detach().numpy()
+        print(tag, kind, "loss %.6f" % float(loss))
+        del model, logits, loss
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **rec)
+
+
+def r3d50_full():
+    """BASELINE config 3's per-GPU geometry at batch 2: R3D-50, 400 classes, 2x3x16x112x112 (Bottleneck kernels in the
+    regimes of the bench: persistent 1x1x1 implicit GEMMs, wide-channel reductions, layer4 at T = 1)."""
+    _whole_net(50, 400, 2, 16, 112, 1357, "r3d50_full")
+
+
+def r3d50_long():
+    """BASELINE config 4's geometry at batch 1: R3D-50, 400 classes, 1x3x64x224x224 (the largest the 8-core build
+    container generates in about a minute)."""
+    _whole_net(50, 400, 1, 64, 224, 9753, "r3d50_long")
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("make_golden.py runs in the build container only (needs %s)" % REF)
@@ -233,6 +275,8 @@ def main():
     ops3d()
     r3d18_small()
     r3d18_full()
+    r3d50_full()
+    r3d50_long()
 
 
 if __name__ == "__main__":

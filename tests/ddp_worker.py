@@ -1,6 +1,15 @@
-"""Worker of tests/test_ddp_gpu.py: one rank, backend nccl (RCCL), VC_DDP_FORCE_COMM=1.
-Runs the same training step with and without DataParallel3D and prints the largest difference of
-the flat gradient / parameter buffers (must be exactly 0: an AVG all-reduce over one rank is the identity)."""
+"""Worker of tests/test_ddp_gpu.py (launched by torch.distributed.run).
+
+  identity : one rank, backend nccl (RCCL), VC_DDP_FORCE_COMM=1.  The same training step plain (twice: the
+             rerun noise), wrapped in DataParallel3D (an AVG all-reduce over one rank is the identity) and wrapped
+             with an INJECTED collective that doubles each bucket on the communication stream: the final gradients
+             must be 2x the plain ones, so a bucket launched before its last gradient was final -- which the identity
+             cannot show -- is off by O(1) in that parameter.  Prints the deviation per parameter.
+  shards   : two ranks (backend gloo, both on cuda:0), each with its own half of the batch, per-rank BatchNorm
+             statistics, gradients averaged by the bucket reducer -- the data-parallel semantics of the reference's
+             torch.nn.DataParallel (train.py:42-43,65).  Rank 0 then repeats the step in one process as two sequential
+             micro-shards with per-shard BatchNorm and averaged gradients, and compares gradients and parameters.
+"""
 import os
 import sys
 
@@ -17,45 +26,120 @@ from utils.utils import create_optimizer  # noqa: E402
 from vc3d.ddp import DataParallel3D  # noqa: E402
 
 
-def run(wrap):
+def build(lr=0.01):
     cfg = config.clone()
     cfg.MODEL.RESNET_TYPE = 18
     cfg.MODEL.CLFDIM = 11
     cfg.MODEL.INIT_WEIGHTS = False
     cfg.TRAIN.OPTIMIZER = "sgd"
-    cfg.TRAIN.LR = 0.01
+    cfg.TRAIN.LR = lr
     torch.manual_seed(3)
     model = create_model(cfg, is_train=True).cuda()
-    crit = Loss(cfg).cuda()
-    opt = create_optimizer(cfg, model)
-    net = DataParallel3D(model, bucket_mb=4) if wrap else model
+    return cfg, model, Loss(cfg).cuda(), create_optimizer(cfg, model)
+
+
+def batch():
     g = torch.Generator().manual_seed(5)
     x = torch.randn(8, 3, 8, 64, 64, generator=g).to(torch.bfloat16).cuda()
     y = torch.randint(0, 11, (8,), generator=g).cuda()
+    return x, y
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def per_param(eng, model, a, b, top=4):
+    """largest relative deviations of flat buffer `a` from `b`, per parameter (name, rel-L2)."""
+    names = {id(p): n for n, p in model.named_parameters()}
+    out = []
+    for p, off, n in eng.grad_ranges:
+        out.append((rel(a[off:off + n], b[off:off + n]), names.get(id(p), "?")))
+    out.sort(reverse=True)
+    return out[:top], out[len(out) // 2]
+
+
+def run_identity(wrap, inject=False):
+    cfg, model, crit, opt = build()
+    net = DataParallel3D(model, bucket_mb=4, tail_mb=0.25, grad_dtype="fp32") if wrap else model
+    x, y = batch()
     net.train()
-    for _ in range(1):  # one step: the fp32-atomic noise of the BatchNorm sums is not yet amplified by training
-        _, score, _ = net(x)
-        loss = crit(score, y, None, None)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+    _, score, _ = net(x)
+    loss = crit(score, y, None, None)
+    opt.zero_grad()
+    if inject:
+        net._ensure().collective = lambda seg: seg.mul_(2)
+    loss.backward()
+    opt.step()
     torch.cuda.synchronize()
     eng = model.backbone.engine
     nb = len(net.reducer.buckets) if wrap else 0
-    return eng.flat_grad.clone(), eng.flat_param.clone(), float(loss), nb
+    return eng, model, eng.flat_grad.clone(), eng.flat_param.clone(), float(loss), nb
 
 
-def main():
+def main_identity():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-    g0, p0, l0, _ = run(False)
-    g2, p2, l2, _ = run(False)
-    g1, p1, l1, nb = run(True)
-    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
-    print("DDP_RESULT grad_rel=%g param_rel=%g rerun_grad_rel=%g rerun_param_rel=%g loss=%g/%g buckets=%d finite=%d" % (
-        rel(g1, g0), rel(p1, p0), rel(g2, g0), rel(p2, p0), l0, l1, nb, int(torch.isfinite(g1).all())), flush=True)
+    eng, model, g0, p0, l0, _ = run_identity(False)
+    _, _, g2, p2, l2, _ = run_identity(False)
+    _, _, g1, p1, l1, nb = run_identity(True)
+    _, _, g3, _, _, _ = run_identity(True, inject=True)
+    for tag, a, b in (("rerun", g2, g0), ("wrapped", g1, g0), ("injected_x2", g3, 2 * g0)):
+        worst, med = per_param(eng, model, a, b)
+        print("DDP_PARAMS %s worst %s median %.3g" % (tag, ["%s=%.3g" % (n, v) for v, n in worst], med[0]), flush=True)
+    print("DDP_RESULT grad_rel=%g param_rel=%g rerun_grad_rel=%g rerun_param_rel=%g inject_rel=%g loss=%g/%g buckets=%d "
+          "finite=%d" % (rel(g1, g0), rel(p1, p0), rel(g2, g0), rel(p2, p0), rel(g3, 2 * g0), l0, l1, nb,
+                         int(torch.isfinite(g1).all())), flush=True)
+    dist.destroy_process_group()
+
+
+def main_shards():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)  # both ranks share the one GPU of the box; gradients travel through gloo
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, y = batch()
+    per = x.shape[0] // world
+    res = {}
+    for dtype in ("fp32", "bf16"):
+        cfg, model, crit, opt = build()
+        net = DataParallel3D(model, bucket_mb=4, tail_mb=0.25, grad_dtype=dtype)
+        net.train()
+        _, score, _ = net(x[rank * per:(rank + 1) * per])
+        loss = crit(score, y[rank * per:(rank + 1) * per], None, None)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        eng = model.backbone.engine
+        res[dtype] = (eng.flat_grad.clone(), eng.flat_param.clone(), len(net.reducer.buckets))
+        # every rank must hold the same averaged gradients
+        mine = eng.flat_grad.cpu()
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert all(torch.equal(both[0], t) for t in both), "ranks disagree on the averaged gradients"
+    if rank == 0:
+        cfg, model, crit, opt = build()
+        model.train()
+        opt.zero_grad()
+        for r in range(world):  # sequential micro-shards: per-shard BatchNorm statistics, gradients accumulate
+            _, score, _ = model(x[r * per:(r + 1) * per])
+            crit(score, y[r * per:(r + 1) * per], None, None).backward()
+        eng = model.backbone.engine
+        eng.flat_grad.div_(world)
+        opt.step()
+        torch.cuda.synchronize()
+        for dtype, (g, p, nb) in res.items():
+            worst, med = per_param(eng, model, g, eng.flat_grad)
+            print("DDP_PARAMS shards_%s worst %s median %.3g" % (dtype, ["%s=%.3g" % (n, v) for v, n in worst], med[0]),
+                  flush=True)
+            print("DDP_SHARDS dtype=%s grad_rel=%g param_rel=%g buckets=%d" % (dtype, rel(g, eng.flat_grad),
+                                                                                rel(p, eng.flat_param), nb), flush=True)
+    dist.barrier()
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "shards":
+        main_shards()
+    else:
+        main_identity()

@@ -188,6 +188,41 @@ def test_full_bench_size_batch_split_property():
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in prod.parameters())
 
 
+@pytest.mark.parametrize("depth,classes,batch,t,hw", [(50, 400, 64, 16, 112), (50, 400, 32, 64, 224)])
+def test_full_size_r3d50_batch_split_property(depth, classes, batch, t, hw):
+    """BASELINE config 3's per-GPU batch (64 x 3 x 16 x 112 x 112, R3D-50, 400 classes) and config 4 at the batch
+    bench.py reports it on (32 x 3 x 64 x 224 x 224): the same size-independent properties as the R3D-18 test above.
+    Eval mode: the logits of the whole batch equal those of its two halves run separately (rel-L2 <= 1e-2, same top-1
+    wherever the top-2 margin exceeds the noise).  Train mode: one step gives a finite loss near ln(classes) and
+    finite gradients in every parameter."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the GPU")
+    import math
+    _, prod, _ = build_pair(depth, classes, device="cuda:0")
+    g = torch.Generator().manual_seed(13)
+    x = torch.empty(batch, 3, t, hw, hw, dtype=torch.bfloat16)
+    for i in range(batch):  # clip by clip: a float32 staging copy of config 4's batch would be 38 GB
+        x[i] = torch.randn(3, t, hw, hw, generator=g).to(torch.bfloat16)
+    x = x.cuda()
+    y = torch.randint(0, classes, (batch,), generator=g).cuda()
+    prod.eval()
+    h = batch // 2
+    with torch.no_grad():
+        full = prod(x)[1].float()
+        halves = torch.cat([prod(x[:h])[1], prod(x[h:])[1]]).float()
+    torch.cuda.synchronize()
+    assert rel_l2(full, halves) <= 1e-2
+    top2 = full.topk(2, dim=1).values
+    sure = (top2[:, 0] - top2[:, 1]) > 2e-2 * full.abs().max()
+    assert bool((full.argmax(1) == halves.argmax(1))[sure].all())
+    prod.train()
+    loss = F.cross_entropy(prod(x)[1], y)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert math.isfinite(float(loss)) and abs(float(loss) - math.log(classes)) <= 0.05 * math.log(classes) + 0.5
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in prod.parameters())
+
+
 def test_fused_and_separate_batchnorm_finalize_agree():
     """the engine's default (BatchNorm finalize done by the last workgroup of the producing launch) against separate
     finalize launches (VC_NO_BN_FIN): same arithmetic on sums that differ only by the arrival order of float atomics,

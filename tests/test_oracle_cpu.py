@@ -149,3 +149,47 @@ def test_bf16_emulation_tracks_fp32_oracle():
     model.load_state_dict(sd)
     lo = model(x)
     assert rel_l2(lo_e, lo) <= 5e-2
+
+
+def test_end_to_end_gradient_floor_of_bf16_operands():
+    """Why no end-to-end gradient test carries north_star's 1e-2 figure.  The fp32 oracle is run twice on the same
+    weights and clips; the second time ONLY the conv operands (inputs and weights) are rounded to bf16 -- storage,
+    accumulation, BatchNorm and every gradient stay fp32.  That is the least any bf16-MFMA convolution does.  At
+    random initialisation the whole-net gradient already moves by tens of percent (measured 0.34 at 2 x 16 x 112 x 112,
+    0.2-0.4 here): about 0.3 % of the ReLU masks flip per layer, a flipped mask moves a whole gradient element, and
+    at initialisation the per-position contributions to a weight gradient add incoherently.  The logits move by 1e-2.
+    So the 1e-2 bar on gradients is applied per kernel and per layer instance on the product's own inputs
+    (tests/test_ops_gpu.py, tests/test_teacher_forced_gpu.py), and end to end the product is held to the CPU
+    bf16-storage emulation (tests/test_net_gpu.py) and to the fp32 training trajectory (tests/test_train_gpu.py)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from oracle.r3d_torch import R3DOracle, init_weights_, synthetic_batch
+
+    class _RoundFwd(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.to(torch.bfloat16).float()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    def grads(round_operands):
+        m = init_weights_(R3DOracle(18, 101), 0).train()
+        if round_operands:
+            for mod in m.modules():
+                if isinstance(mod, nn.Conv3d):
+                    mod.forward = (lambda c: lambda inp: F.conv3d(_RoundFwd.apply(inp), _RoundFwd.apply(c.weight), None,
+                                                                  c.stride, c.padding))(mod)
+        x, y = synthetic_batch(2, 8, 64, 64, 101, 2468)
+        lo = m(x)
+        F.cross_entropy(lo, y).backward()
+        return lo.detach(), torch.cat([p.grad.flatten() for p in m.parameters()]).double()
+
+    l0, g0 = grads(False)
+    l1, g1 = grads(True)
+    e_logit = float((l1 - l0).norm() / l0.norm())
+    e_grad = float((g1 - g0).norm() / g0.norm())
+    print("bf16 conv operands only: logits rel-L2 %.3e, whole-net gradient rel-L2 %.3e" % (e_logit, e_grad))
+    assert e_logit <= 5e-2
+    assert e_grad >= 3e-2, "the gradient floor of bf16 operands was expected to exceed north_star's 1e-2 figure"

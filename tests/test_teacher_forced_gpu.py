@@ -167,5 +167,11 @@ def test_r3d50_teacher_forced():
     _run(50, 400, n=2, t=8, hw=64)
 
 
+def test_r3d50_teacher_forced_16x112x112():
+    """BASELINE config 3's geometry: every Bottleneck kernel instance (persistent 1x1x1 implicit GEMMs, wide-channel
+    BatchNorm reductions, 1x1x1 weight gradients with many slabs, layer4 at T = 1) against fp32 torch on its own inputs."""
+    _run(50, 400, n=2, t=16, hw=112)
+
+
 def test_r3d34_teacher_forced_forward_only():
     _run(34, 101, n=2, t=4, hw=64, backward=False)

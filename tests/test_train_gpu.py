@@ -200,3 +200,42 @@ def test_eval_after_training_uses_current_batchnorm_parameters():
     print("eval drift between the two evals %.3e, second eval vs fresh model %.3e" % (rel_l2(e2, e1), rel_l2(e2, ef)))
     assert rel_l2(e2, e1) > 1e-2, "the model was expected to move between the two evaluations"
     assert rel_l2(e2, ef) <= 1e-3
+
+
+def test_training_trajectory_tracks_the_fp32_oracle():
+    """Is bf16 storage + bf16 MFMA "good enough" for training?  Same initial weights, same fixed batch, same SGD
+    (momentum 0.9): the product path on the GPU and the fp32 torch oracle on the CPU are trained side by side for 16
+    steps.  Single gradients cannot be compared tightly at random initialisation (tests/test_net_gpu.py,
+    tests/test_oracle_cpu.py::test_end_to_end_gradient_floor_of_bf16_operands); what training needs is that the loss
+    follows the fp32 trajectory: every one of the first 8 losses within 5 % + 0.05 of the oracle's, and the batch is
+    fitted as well as the oracle fits it (final loss <= 1.5 x the oracle's + 0.1)."""
+    from helpers import build_pair
+    from oracle.r3d_torch import synthetic_batch
+    from utils.utils import create_optimizer
+    oracle, prod, cfg = build_pair(18, 8)
+    cfg.TRAIN.OPTIMIZER, cfg.TRAIN.LR, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WD, cfg.TRAIN.NESTEROV = "sgd", 0.02, 0.9, 1e-4, False
+    opt = create_optimizer(cfg, prod)
+    topt = torch.optim.SGD(oracle.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    x, y = synthetic_batch(8, 8, 64, 64, 8, 77)
+    xc, yc = x.cuda(), y.cuda()
+    oracle.train()
+    prod.train()
+    lp, lr_ = [], []
+    for _ in range(16):
+        _, score, _ = prod(xc)
+        loss = F.cross_entropy(score, yc)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        lp.append(float(loss))
+        lo = F.cross_entropy(oracle(x), y)
+        topt.zero_grad()
+        lo.backward()
+        topt.step()
+        lr_.append(float(lo))
+    print("product", ["%.3f" % v for v in lp])
+    print("oracle ", ["%.3f" % v for v in lr_])
+    for a, b in list(zip(lp, lr_))[:8]:
+        assert abs(a - b) <= 0.05 * b + 0.05
+    assert lr_[-1] < 0.5 * lr_[0], "the oracle itself was expected to fit the batch"
+    assert lp[-1] <= 1.5 * lr_[-1] + 0.1

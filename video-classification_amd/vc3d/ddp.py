@@ -18,6 +18,7 @@ streams live, two of them share a queue and the overlap turns into head-of-line 
 MI355X with the buckets forced on: 6.70 ms/step at 4 queues, 6.02 at 8).  The entry points (bench.py, train.py,
 valid.py) therefore default GPU_MAX_HW_QUEUES to 8 before the HIP runtime starts.
 """
+import contextlib
 import os
 
 import torch
@@ -29,28 +30,49 @@ FORCE_COMM = os.environ.get("VC_DDP_FORCE_COMM", "0") == "1"
 
 
 class GradBucketReducer:
-    def __init__(self, flat, ranges, group=None, bucket_bytes=32 << 20):
+    """Buckets = contiguous slices of the flat fp32 gradient buffer, in the order the engine finishes them.
+
+    Sizes (xGMI arithmetic, SURVEY section 5: 7 links x ~153 GB/s per GPU, point to point).  R3D-50 has 46 M parameters:
+    185 MB of fp32 gradients, 92 MB as bf16.  An 8-GPU all-reduce moves 2 x 7/8 of the message per GPU; RCCL spreads it
+    over rings on different links, so a LARGE message sees a few hundred GB/s of bus bandwidth (92 MB in about
+    0.5 ms), a small one only its latency (tens of microseconds per ring step): buckets of 32 MB keep the bandwidth
+    term dominant, and 3-6 of them per step keep every all-reduce but the last behind the rest of backward (12 ms
+    today, 3 ms at the MFMA target).  What cannot be hidden is the LAST bucket -- it is launched when backward ends --
+    so the buckets are cut from the end: the final one holds at most `tail_bytes` (the stem and layer1, whose
+    gradients are small and finish last), about 20 us of exposed all-reduce instead of a full bucket's.
+    `grad_dtype` = "bf16" halves the bytes on the wire: the slice is rounded into a bf16 staging buffer on the
+    communication stream, averaged there, and written back to the fp32 buffer (the optimizer's master gradients and
+    parameters stay fp32; 2^-9 relative rounding per element, below the bf16 noise already in the gradients)."""
+
+    def __init__(self, flat, ranges, group=None, bucket_bytes=32 << 20, tail_bytes=4 << 20, grad_dtype="fp32"):
         """flat: the flat gradient tensor; ranges: [(key, offset, numel)] in readiness order."""
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        if grad_dtype not in ("fp32", "bf16"):
+            raise ValueError("grad_dtype must be 'fp32' or 'bf16'")
+        self.grad_dtype = grad_dtype
+        self.collective = None  # test hook: callable(slice) run on the communication stream in place of the all-reduce
+        self.enabled = True     # False inside DataParallel3D.no_sync()
+        esz = flat.element_size()
+        # cut from the end so that the bucket that finishes last (exposed at the end of backward) is the small one
+        cuts, limit, hi = [], tail_bytes, None
+        for i in range(len(ranges) - 1, -1, -1):
+            _, off, n = ranges[i]
+            if hi is None:
+                hi, hi_i = off + n, i
+            if (hi - off) * esz >= limit or i == 0:
+                cuts.append((i, hi_i, off, hi))
+                hi, limit = None, bucket_bytes
         self.buckets = []  # [start, end, nparams]
         self.key2bucket = {}
-        cur_start, cur_n = 0, 0
-        esz = flat.element_size()
-        for key, off, n in ranges:
-            if cur_n == 0:
-                cur_start = off
-            self.key2bucket[key] = len(self.buckets)
-            cur_n += 1
-            if (off + n - cur_start) * esz >= bucket_bytes:
-                self.buckets.append([cur_start, off + n, cur_n])
-                cur_n = 0
-        if cur_n:
-            last_key, off, n = ranges[-1]
-            self.buckets.append([cur_start, off + n, cur_n])
+        for lo_i, hi_i, start, end in reversed(cuts):
+            for i in range(lo_i, hi_i + 1):
+                self.key2bucket[ranges[i][0]] = len(self.buckets)
+            self.buckets.append([start, end, hi_i - lo_i + 1])
         self.comm_stream = torch.cuda.Stream() if flat.is_cuda else None
+        self.comm_buf = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device) if grad_dtype == "bf16" else None
         self.producer_streams = lambda: ()  # extra streams that write gradients (the engine's weight-gradient stream)
         self.reset()
 
@@ -60,6 +82,8 @@ class GradBucketReducer:
         self.launched = [False] * len(self.buckets)
 
     def on_ready(self, key):
+        if not self.enabled:
+            return
         b = self.key2bucket.get(key)
         if b is None:
             return
@@ -67,11 +91,27 @@ class GradBucketReducer:
         if self.pending[b] == 0:
             self._launch(b)
 
+    def _reduce(self, seg, start, end):
+        """average `seg` over the group, on the current (communication) stream / thread."""
+        if self.collective is not None:
+            self.collective(seg)
+            return
+        buf = seg if self.comm_buf is None else self.comm_buf[start:end]
+        if buf is not seg:
+            buf.copy_(seg)  # fp32 -> bf16, one rounding
+        if self.backend == "nccl":
+            dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)  # enqueued behind this stream, no host wait
+        else:  # gloo (tests): no AVG; the call returns when the result is in place
+            dist.all_reduce(buf, group=self.group)
+            buf.div_(self.world)
+        if buf is not seg:
+            seg.copy_(buf)
+
     def _launch(self, b):
         if self.launched[b]:
             return
         self.launched[b] = True
-        if self.world == 1 and not (FORCE_COMM and dist.is_initialized()):
+        if self.collective is None and self.world == 1 and not (FORCE_COMM and dist.is_initialized()):
             return
         start, end, _ = self.buckets[b]
         seg = self.flat[start:end]
@@ -87,26 +127,19 @@ class GradBucketReducer:
             with torch.cuda.stream(self.comm_stream):
                 for ev in evs:
                     self.comm_stream.wait_event(ev)
-                if self.backend == "nccl":
-                    w = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-                else:
-                    w = dist.all_reduce(seg, group=self.group, async_op=True)
-            self.works.append((w, seg))
+                self._reduce(seg, start, end)
+            self.works.append(b)
         else:
-            dist.all_reduce(seg, group=self.group)
-            seg.div_(self.world)
+            self._reduce(seg, start, end)
 
     def finish(self):
         """flush buckets that never filled (unused parameters), then join the side stream."""
+        if not self.enabled:
+            return
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)
         if self.flat.is_cuda and self.works:
-            for w, seg in self.works:
-                with torch.cuda.stream(self.comm_stream):
-                    w.wait()
-                    if self.backend != "nccl":
-                        seg.div_(self.world)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.reset()
 
@@ -125,12 +158,16 @@ class DataParallel3D(torch.nn.Module):
     ``torch.nn.DataParallel(model, device_ids=gpus).cuda()`` of the reference (train.py:43), except
     that every rank constructs it on its own GPU."""
 
-    def __init__(self, model, group=None, bucket_mb=32):
+    def __init__(self, model, group=None, bucket_mb=32, tail_mb=4, grad_dtype=None):
         super().__init__()
         self.module = model
         self.group = group
         self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self.tail_bytes = int(tail_mb * (1 << 20))
+        # gradients travel as bf16 by default (half the xGMI bytes; fp32 master gradients); VC_DDP_GRAD_DTYPE=fp32 opts out
+        self.grad_dtype = grad_dtype or os.environ.get("VC_DDP_GRAD_DTYPE", "bf16")
         self.reducer = None
+        self._sync = True
         broadcast_module(model, 0, group)
         eng = model.backbone.engine
         eng.grad_ready_cb = self._on_ready
@@ -140,17 +177,33 @@ class DataParallel3D(torch.nn.Module):
         eng = self.module.backbone.engine
         if self.reducer is None or self.reducer.flat is not eng.flat_grad:
             ranges = [(id(p), off, n) for p, off, n in eng.grad_ranges]
-            self.reducer = GradBucketReducer(eng.flat_grad, ranges, self.group, self.bucket_bytes)
+            self.reducer = GradBucketReducer(eng.flat_grad, ranges, self.group, self.bucket_bytes, self.tail_bytes,
+                                             self.grad_dtype)
             # gradients are written on the stream backward runs on (BatchNorm, head) and on the engine's side
             # stream (conv weights); a ready callback may come from inside either stream's context
             self.reducer.producer_streams = lambda: (eng._side, eng._main)
         return self.reducer
 
     def _on_ready(self, p):
-        self._ensure().on_ready(id(p))
+        r = self._ensure()
+        r.enabled = self._sync
+        r.on_ready(id(p))
 
     def _on_done(self):
-        self._ensure().finish()
+        r = self._ensure()
+        r.enabled = self._sync
+        r.finish()
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """gradient accumulation (torch DDP's no_sync): backward passes inside the context only accumulate into the
+        flat gradient buffer; the first backward outside it averages the accumulated sum.  Without it every backward
+        all-reduces whatever the buffer holds, which would average an already averaged gradient a second time."""
+        keep, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = keep
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
