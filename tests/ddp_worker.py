@@ -38,10 +38,10 @@ def build(lr=0.01):
     return cfg, model, Loss(cfg).cuda(), create_optimizer(cfg, model)
 
 
-def batch():
+def batch(n=8):
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(8, 3, 8, 64, 64, generator=g).to(torch.bfloat16).cuda()
-    y = torch.randint(0, 11, (8,), generator=g).cuda()
+    x = torch.randn(n, 3, 8, 64, 64, generator=g).to(torch.bfloat16).cuda()
+    y = torch.randint(0, 11, (n,), generator=g).cuda()
     return x, y
 
 
@@ -97,7 +97,7 @@ def main_shards():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)  # both ranks share the one GPU of the box; gradients travel through gloo
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    x, y = batch()
+    x, y = batch(16)  # 8 clips per rank: the size at which a plain step repeats itself (see DDP_CHECK rerun below)
     per = x.shape[0] // world
     res = {}
     for dtype in ("fp32", "bf16"):
@@ -128,6 +128,25 @@ def main_shards():
         eng.flat_grad.div_(world)
         opt.step()
         torch.cuda.synchronize()
+        # third form: each micro-shard in a fresh model, gradients averaged on the host side of the comparison
+        singles = []
+        for r in range(world):
+            _, m2, crit2, opt2 = build()
+            m2.train()
+            opt2.zero_grad()
+            _, score, _ = m2(x[r * per:(r + 1) * per])
+            crit2(score, y[r * per:(r + 1) * per], None, None).backward()
+            torch.cuda.synchronize()
+            singles.append(m2.backbone.engine.flat_grad.clone())
+        avg = sum(singles) / world
+        _, m3, crit3, opt3 = build()  # shard 0 once more: the run-to-run noise of this configuration
+        m3.train()
+        opt3.zero_grad()
+        crit3(m3(x[:per])[1], y[:per], None, None).backward()
+        torch.cuda.synchronize()
+        print("DDP_CHECK rerun=%g accumulate_vs_separate=%g ddp_fp32_vs_separate=%g shard0_vs_shard1=%g" % (
+            rel(m3.backbone.engine.flat_grad, singles[0]), rel(eng.flat_grad, avg), rel(res["fp32"][0], avg),
+            rel(singles[0], singles[1])), flush=True)
         for dtype, (g, p, nb) in res.items():
             worst, med = per_param(eng, model, g, eng.flat_grad)
             print("DDP_PARAMS shards_%s worst %s median %.3g" % (dtype, ["%s=%.3g" % (n, v) for v, n in worst], med[0]),
@@ -139,6 +158,8 @@ def main_shards():
 
 
 if __name__ == "__main__":
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)  # a stuck collective names itself instead of hanging the box
     if len(sys.argv) > 1 and sys.argv[1] == "shards":
         main_shards()
     else:

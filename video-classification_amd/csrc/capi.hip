@@ -487,7 +487,9 @@ int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, floa
                 q.partial_stride = (long long)dw_e9;
                 rc = vc_launch_wgrad9(q, S(stream));
                 if (rc) return rc;
-                return vc_ew_splitk_reduce_wgrad(q.partial, s9, q.partial_stride, dw, (long)dw_e9, S(stream));
+                // T == 1: only the nine dt = 0 taps are computed; the other slab entries hold whatever the workspace held
+                return vc_ew_splitk_reduce_wgrad(q.partial, s9, q.partial_stride, dw, (long)dw_e9, d->Ci, 27,
+                                                 q.ndt == 3 ? 0x7ffffffu : (0x1ffu << 9), S(stream));
             }
             return vc_launch_wgrad9(q, S(stream));  // no workspace: float atomics when split
         }
@@ -515,6 +517,8 @@ int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, floa
                 t.wk_off = i * d->Ci;
             }
     p.ntaps = nlive;
+    unsigned live_mask = 0;
+    for (int t = 0; t < nlive; ++t) live_mask |= 1u << (p.taps[t].wk_off / d->Ci);
     int rps;
     const int splits = vc_wgrad_splits(p.M, p.Co, live_taps(d) * (d->Ci / 64), &rps);
     const size_t dw_e = (size_t)d->Co * p.Kw;
@@ -523,7 +527,8 @@ int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, floa
         p.partial_stride = (long long)dw_e;
         rc = vc_launch_wgrad(p, 0, S(stream));
         if (rc) return rc;
-        return vc_ew_splitk_reduce_wgrad(p.partial, splits, p.partial_stride, dw, (long)dw_e, S(stream));
+        return vc_ew_splitk_reduce_wgrad(p.partial, splits, p.partial_stride, dw, (long)dw_e, d->Ci, d->kt * d->kh * d->kw,
+                                         live_mask, S(stream));
     }
     return vc_launch_wgrad(p, 0, S(stream));
 }

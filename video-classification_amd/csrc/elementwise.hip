@@ -228,13 +228,18 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 // dependent chain, 19 us for 64 KB of output), PH = 4 otherwise.
 template <int PH>
 __global__ __launch_bounds__(256) void splitk_reduce_wgrad_kernel(const float* __restrict__ slabs, int splits,
-                                                                  long long stride, float* __restrict__ dw, long n4) {
+                                                                  long long stride, float* __restrict__ dw, long n4,
+                                                                  int ci4, int taps, unsigned live) {
     constexpr int NP = 256 / PH;
     __shared__ f32x4 part[PH - 1][NP];
     const int q = threadIdx.x / NP, l = threadIdx.x % NP;
     const long i = (long)blockIdx.x * NP + l;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (i < n4) {
+    // `live` (bit t: tap t of [Co][taps][Ci] was computed): the weight-gradient kernels never write the slab entries
+    // of a dropped tap (one that only ever reads zero padding), so those are neither read nor added: dw stays as it is
+    bool on = i < n4;
+    if (on && live != 0xffffffffu) on = ((live >> (unsigned)((i / ci4) % taps)) & 1u) != 0u;
+    if (on) {
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
         int z = q;
         for (; z + PH < splits; z += 2 * PH) {
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_wgrad_kernel(const float* _
     }
     if (q > 0) part[q - 1][l] = s;
     __syncthreads();
-    if (q == 0 && i < n4) {
+    if (q == 0 && on) {
 #pragma unroll
         for (int k = 0; k < PH - 1; ++k) s += part[k][l];
         f32x4 o = ((const f32x4*)dw)[i];
@@ -1092,13 +1097,16 @@ int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void
                   accumulate, stats, rows, C, slices, VcBnFin{});
     return VC_CHECK_LAUNCH();
 }
-int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, hipStream_t s) {
+int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, int Ci, int taps,
+                              unsigned live, hipStream_t s) {
+    if (taps <= 0 || taps > 32 || Ci % 4 != 0) live = 0xffffffffu, taps = 1, Ci = 4;
+    else if (taps < 32 && live == (1u << taps) - 1u) live = 0xffffffffu;  // every tap computed: no test in the kernel
     if (splits >= 32)
         VC_LAUNCH((splitk_reduce_wgrad_kernel<16>), dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, s, slabs, splits,
-                  stride, dw, n / 4);
+                  stride, dw, n / 4, Ci / 4, taps, live);
     else
         VC_LAUNCH((splitk_reduce_wgrad_kernel<4>), dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, slabs, splits,
-                  stride, dw, n / 4);
+                  stride, dw, n / 4, Ci / 4, taps, live);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_bwd_finalize(const float* sums, int C, float count, float* coef, float* dgamma, float* dbeta,

@@ -227,5 +227,5 @@ int vc_launch_stem_wgrad(VcStemWgradParams& p, float* dws, hipStream_t stream) {
         return -1;
     }
     // dws += sum of the workgroups' slabs
-    return vc_ew_splitk_reduce_wgrad(p.slabs, p.grid, (long long)64 * 1344, dws, 64L * 1344, stream);
+    return vc_ew_splitk_reduce_wgrad(p.slabs, p.grid, (long long)64 * 1344, dws, 64L * 1344, 0, 0, 0xffffffffu, stream);
 }

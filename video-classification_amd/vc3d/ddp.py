@@ -101,7 +101,11 @@ class GradBucketReducer:
             buf.copy_(seg)  # fp32 -> bf16, one rounding
         if self.backend == "nccl":
             dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)  # enqueued behind this stream, no host wait
-        else:  # gloo (tests): no AVG; the call returns when the result is in place
+        elif buf.is_cuda:  # gloo with device memory (tests: ranks sharing one GPU): staged through the host
+            host = buf.cpu()  # waits for this stream, i.e. for the gradients of the bucket
+            dist.all_reduce(host, group=self.group)
+            buf.copy_(host.div_(self.world))
+        else:  # gloo on host memory: no AVG
             dist.all_reduce(buf, group=self.group)
             buf.div_(self.world)
         if buf is not seg:
@@ -148,9 +152,15 @@ def broadcast_module(module, src=0, group=None):
     """one-time replica initialisation: parameters and buffers from rank `src`."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    staged = dist.get_backend(group) != "nccl"  # gloo's device-memory collectives hang between ranks that share a GPU
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src, group=group)
+            if staged and t.is_cuda:
+                host = t.data.cpu()
+                dist.broadcast(host, src, group=group)
+                t.data.copy_(host)
+            else:
+                dist.broadcast(t.data, src, group=group)
 
 
 class DataParallel3D(torch.nn.Module):
