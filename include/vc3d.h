@@ -85,6 +85,18 @@ int vc_conv3d_fwd_bn(const vc_conv3d_desc* d, const void* x, const void* w, void
  * No separate vc_bn_apply pass.  (Split-K geometries apply it in place after the conv.) */
 int vc_conv3d_fwd_act(const vc_conv3d_desc* d, const void* x, const void* w, void* y, const float* bn_params,
                       const void* residual, int32_t relu, void* workspace, size_t ws_bytes, void* stream);
+/* No counterpart in the reference: vc_conv3d_fwd for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc) and so have no workspace to bring.  The split-K partial
+ * slabs live in a file-scope device array of VC_STATIC_SCRATCH_BYTES that the library holds on every GPU it runs on
+ * until the process ends; the call itself allocates nothing.  Same kernels, same split plan and therefore the same
+ * bits in y as vc_conv3d_fwd with a workspace of vc_conv3d_workspace_bytes(d, 0).  A geometry whose plan needs more
+ * than VC_STATIC_SCRATCH_BYTES is rejected (-3, message in vc_last_error) -- it is never silently run unsplit.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
+ * serialise them or use vc_conv3d_fwd.  Nothing is kept between calls (the array needs no clearing). */
+#define VC_STATIC_SCRATCH_BYTES (64u << 20)
+size_t vc_static_scratch_bytes(void);
+int vc_conv3d_fwd_noalloc(const vc_conv3d_desc* d, const void* x, const void* w, void* y,
+                          float* bn_stats /* nullable */, void* stream);
 int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx,
                     int accumulate /* dx += instead of dx = */, void* workspace, size_t ws_bytes,
                     void* stream);

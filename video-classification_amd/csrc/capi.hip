@@ -1,6 +1,7 @@
 // extern "C" entry points of libvc3d.so (declared in include/vc3d.h): validate shapes on the
 // host, build the gather descriptions and launch.  Nothing here allocates or synchronises.
 #include <stdarg.h>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -298,6 +299,62 @@ int vc_conv3d_fwd_bn(const vc_conv3d_desc* d, const void* x, const void* w, void
     int rc = make_fin(fin, bn_stats, f);
     if (rc) return rc;
     return conv3d_fwd_impl(d, x, w, y, bn_stats, &f, nullptr, 0, nullptr, workspace, ws_bytes, stream);
+}
+
+}  // extern "C"
+
+/* ---- the entry point that allocates nothing (no counterpart in the reference; see include/vc3d.h) ----
+ * The split-K partial slabs of vc_conv3d_fwd live in a file-scope device array instead of a caller workspace.
+ * `vc_static_scratch` below is the HOST-side stand-in of that array: it is never handed to a kernel or a memset;
+ * every device holds its own copy at its own address, looked up once per device with hipGetSymbolAddress (that
+ * device current) and kept in g_scratch_ptr[]. */
+static __device__ __align__(256) unsigned char vc_static_scratch[VC_STATIC_SCRATCH_BYTES];
+static void* g_scratch_ptr[64];
+static std::once_flag g_scratch_once[64];
+
+static int static_scratch(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        vc_set_error("static scratch: no current device (or device index %d >= 64)", dev);
+        return -1;
+    }
+    hipError_t err = hipSuccess;
+    std::call_once(g_scratch_once[dev], [&]() {
+        void* ptr = nullptr;
+        err = hipGetSymbolAddress(&ptr, HIP_SYMBOL(vc_static_scratch));
+        g_scratch_ptr[dev] = err == hipSuccess ? ptr : nullptr;
+    });
+    if (g_scratch_ptr[dev] == nullptr) {
+        vc_set_error("static scratch: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(err));
+        return -1;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+extern "C" {
+
+size_t vc_static_scratch_bytes(void) { return VC_STATIC_SCRATCH_BYTES; }
+
+int vc_conv3d_fwd_noalloc(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, void* stream) {
+    int To, Ho, Wo;
+    int rc = conv_check(d, To, Ho, Wo);
+    if (rc) return rc;
+    const size_t need = vc_conv3d_workspace_bytes(d, 0);
+    if (need == 0)  // this geometry is not split: no scratch involved at all
+        return conv3d_fwd_impl(d, x, w, y, bn_stats, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
+    if (need > (size_t)VC_STATIC_SCRATCH_BYTES) {
+        vc_set_error("conv3d_fwd_noalloc: this geometry needs %zu bytes of split-K scratch, the static scratch holds %zu; "
+                     "use vc_conv3d_fwd with a caller-owned workspace (or a smaller batch)",
+                     need, (size_t)VC_STATIC_SCRATCH_BYTES);
+        return -3;
+    }
+    void* scratch = nullptr;
+    rc = static_scratch(&scratch);
+    if (rc) return rc;
+    // nothing in the scratch has to start at zero: every slab element that the finalize kernel reads is written by
+    // the conv kernel of the same call first (stream order)
+    return conv3d_fwd_impl(d, x, w, y, bn_stats, nullptr, nullptr, 0, nullptr, scratch, (size_t)VC_STATIC_SCRATCH_BYTES, stream);
 }
 
 }  // extern "C"

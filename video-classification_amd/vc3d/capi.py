@@ -69,6 +69,8 @@ PROTOTYPES = {
     "vc_conv3d_fwd": [_CD, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "vc_conv3d_fwd_bn": [_CD, _P, _P, _P, _P, _BF, _P, C.c_size_t, _P],
     "vc_conv3d_fwd_act": [_CD, _P, _P, _P, _P, _P, _I, _P, C.c_size_t, _P],
+    "vc_static_scratch_bytes": [],
+    "vc_conv3d_fwd_noalloc": [_CD, _P, _P, _P, _P, _P],
     "vc_conv3d_dgrad": [_CD, _P, _P, _P, _I, _P, C.c_size_t, _P],
     "vc_conv3d_wgrad": [_CD, _P, _P, _P, _P, C.c_size_t, _P],
     "vc_pack_weight": [_P, _P, _P, _I, _I, _I, _P],
@@ -106,7 +108,7 @@ PROTOTYPES = {
     "vc_ncthw_to_nthwc": [_P, _I, _P, _I, _I, _L, _P],
     "vc_nthwc_to_ncthw": [_P, _P, _I, _I, _I, _L, _P],
 }
-_RESTYPE = {"vc_last_error": C.c_char_p, "vc_stem_packed_input_elems": C.c_size_t,
+_RESTYPE = {"vc_last_error": C.c_char_p, "vc_stem_packed_input_elems": C.c_size_t, "vc_static_scratch_bytes": C.c_size_t,
             "vc_conv3d_workspace_bytes": C.c_size_t, "vc_stem_wgrad_workspace_bytes": C.c_size_t}
 
 
