@@ -26,12 +26,14 @@ raw.vc_debug_halo_stamps(None)
 b = buf.view(-1, 8).cpu()
 b = b[b[:, 0] != 0]
 t0 = b[:, 0].min()
-names = ["masks", "acc0/issue", "issue halo+W", "halo landed", "tap loop", "(chunk end)", "epilogue"]
-print("workgroups", b.shape[0], "span (all WGs) %d ticks" % int(b[:, 6].max() - t0))
-for k in range(6):
-    dlt = (b[:, k + 1] - b[:, k]).double()
-    print("%-14s median %8.0f  mean %8.0f  max %8.0f" % (names[k], dlt.median(), dlt.mean(), dlt.max()))
-tot = (b[:, 6] - b[:, 0]).double()
-print("per-WG total    median %8.0f  mean %8.0f" % (tot.median(), tot.mean()))
-st = (b[:, 0] - t0).double().sort().values
-print("WG start offsets: 25%% %d  50%% %d  75%% %d  max %d" % tuple(int(st[int(q * (len(st) - 1))]) for q in (0.25, 0.5, 0.75, 1.0)))
+names = ["masks", "issue c0", "c0 landed", "c0 tap loop", "c1 issue+landed", "c1 tap loop", "epilogue"]
+print("workgroups", b.shape[0])
+two = bool((b[:, 5] != 0).any())
+for k in range(7):
+    if not two and k in (4, 5):
+        continue
+    lo = b[:, k] if (two or k != 6) else b[:, 4]
+    dlt = (b[:, k + 1] - lo).double()
+    print("%-16s median %8.0f  mean %8.0f  max %8.0f" % (names[k], dlt.median(), dlt.mean(), dlt.max()))
+tot = (b[:, 7] - b[:, 0]).double()
+print("per-WG total     median %8.0f  mean %8.0f" % (tot.median(), tot.mean()))

@@ -66,13 +66,29 @@ __device__ __forceinline__ float row16_sum(float v) {
 #define VC_HALO_ABLATE 0  // timing experiments only (scripts/halo_ablate.sh): 1 no tap barrier, 2 no image reads, 4 no weight reads, 8 no weight DMA, 16 no MFMA
 #endif
 
-// PAD: the LDS image is stored zero-padded -- (R + 2) x (W + 2) rows per plane, out-of-sample rows filled
+// PAD: the LDS image is stored zero-padded -- (R + 2) x (W + 1) + 1 rows per plane, out-of-sample rows filled
 // from the zero page by the loader -- so a tap is a pure row shift: no validity masks, no per-tap selects
 // (the tap loop is VALU-issue bound otherwise).  Needs whole-h-row segments and TT | T.
-template <int NW, int CK, bool PAD>
+// reads / MFMAs of one pipeline stage interleaved in program order: R fragment reads spread evenly over M MFMAs
+template <int I, int R, int M>
+struct HaloSched {
+    static __device__ __forceinline__ void run() {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        constexpr int n = ((I + 1) * M) / R - (I * M) / R;
+        if constexpr (n > 0) __builtin_amdgcn_sched_group_barrier(0x008, n, 0);
+        if constexpr (I + 1 < R) HaloSched<I + 1, R, M>::run();
+    }
+};
+
+// NB = 16-position blocks per wave: the wave tile is 64 co x NB*16 positions (NB*4 accumulator quads).  NB = 4 with
+// eight waves is the one-workgroup-per-CU form; NB = 7 / 8 with four waves and 32-channel chunks (64-byte image rows)
+// halves the LDS of a workgroup, so TWO workgroups share a CU: one's image fill, barriers and epilogue run beside
+// the other's MFMAs, and a wave reads 4 weight + NB activation fragments per 4*NB MFMAs instead of 4 + 4 per 16.
+template <int NW, int CK, bool PAD, int NB>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void halo_conv_kernel(const VcHaloParams p) {
-    static_assert(!PAD || CK == 64, "the padded image form is built for 128-byte rows");
     using Cfg = HaloCfg<CK>;
+    constexpr int WS = NB * 16;  // position slots per wave
+    constexpr int RSH = CK == 64 ? 7 : 6;  // log2 of the image row pitch in bytes
     constexpr int ROWB = Cfg::ROWB, WBUF = Cfg::WBUF, ZERO_OFF = Cfg::ZERO_OFF, HALO_OFF = Cfg::HALO_OFF, PR = Cfg::PR,
                   KS = Cfg::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,14 +120,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     } while (0)
     VC_STAMP(0);
 
-    // ---- per-lane output slots: 4 positions (b = 0..3), row = wave*64 + b*16 + l15
-    int lrow0[4];        // LDS image row of the slot's own position (tap 0,0,0); PAD: its byte offset (row << 7)
-    unsigned mask[4];    // bit i: tap i reads inside the sample (unused with PAD)
-    int ooff[4];         // element offset of the output row, -1 = idle slot
+    // ---- per-lane output slots: NB positions (b = 0..NB-1), row = wave*WS + b*16 + l15
+    int lrow0[NB];        // LDS image row of the slot's own position (tap 0,0,0); PAD: its byte offset (row << RSH)
+    unsigned mask[NB];    // bit i: tap i reads inside the sample (unused with PAD)
+    int ooff[NB];         // element offset of the output row, -1 = idle slot
     if constexpr (PAD) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int slot = wave * 64 + b * 16 + l15;
+        for (int b = 0; b < NB; ++b) {
+            const int slot = wave * WS + b * 16 + l15;
             const int tp = (int)vc_div((unsigned)slot, p.dSEG);
             const int s = slot - tp * p.SEG;
             const int hl = (int)vc_div((unsigned)s, p.dW);
@@ -119,15 +135,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const int P = P0 + tp;
             const bool ok = tp < p.TT && P < p.NP;
             // idle slot: the tile's first position (every tap stays inside the image; the result is dropped)
-            lrow0[b] = (ok ? (tp + 1) * p.HR + (hl + 1) * p.Wp + (w + 1) : p.HR + p.Wp + 1) << 7;
+            lrow0[b] = (ok ? (tp + 1) * p.HR + (hl + 1) * p.Wp + (w + 1) : p.HR + p.Wp + 1) << RSH;
             ooff[b] = ok ? (P * HW + s0 + s) * p.Cn : -1;
             mask[b] = 0;
         }
     } else {
-    int pt_[4], ph_[4], pw_[4];
+    int pt_[NB], ph_[NB], pw_[NB];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int slot = wave * 64 + b * 16 + l15;
+    for (int b = 0; b < NB; ++b) {
+        const int slot = wave * WS + b * 16 + l15;
         const int tp = (int)vc_div((unsigned)slot, p.dSEG);
         const int s = slot - tp * p.SEG;
         const int P = P0 + tp;
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // canonical 3x3x3 table (tap i = (a*3 + b)*3 + c with offsets a-1, b-1, c-1, or all negated):
         // the 27-bit mask is the outer product of three 3-bit per-axis validity masks
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < NB; ++b) {
             unsigned vt = 0, vh = 0, vw = 0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const int ot = (int)(signed char)(o3 & 0xff), oh = (int)(signed char)((o3 >> 8) & 0xff),
                       ow = (int)(signed char)((o3 >> 16) & 0xff);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 const bool in = (unsigned)(pt_[b] + ot) < (unsigned)p.T && (unsigned)(ph_[b] + oh) < (unsigned)p.H &&
                                 (unsigned)(pw_[b] + ow) < (unsigned)p.W;
                 mask[b] |= in ? (1u << i) : 0u;
@@ -193,7 +209,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     auto issue_halo = [&](int cch) {
         char* dst = smem + HALO_OFF;
         if constexpr (PAD) {
-            // image row r = (q*(R+2) + hh)*(W+2) + ww  ->  plane P0-1+q, row h0-1+hh, column ww-1; zero outside
+            // image row r = q*HR + hh*(W+1) + ww, HR = (R+2)*(W+1) + 1  ->  plane P0-1+q, row h0-1+hh, column ww-1; zero
+            // outside.  ONE zero column per h-row: column 0 is the left neighbour of w = 0 and, being the element after
+            // the previous row's w = W-1, that row's right neighbour too; the plane's last row gets one trailing element.
             const int p0t = P0 - (int)vc_div((unsigned)P0, p.dT) * p.T;
             const int h0 = sg * p.R;
             for (int pc = wave; pc < p.npieces; pc += NW) {
@@ -204,8 +222,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const int w = u - hh * p.Wp - 1;
                 const int h = h0 - 1 + hh;
                 const int P = P0 - 1 + q;
+                // hh == R + 2: the one trailing element of a plane (the right neighbour of its last row's last column)
                 const bool ok = r < p.halo_rows && (q >= 1 || p0t != 0) && (q <= p.TT || p0t + p.TT != p.T) && P < p.NP &&
-                                (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                                hh < p.R + 2 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
                 const long grow = (long)P * HW + h * p.W + w;
                 const int ls = pslot ^ Cfg::swz(r);
                 const gptr_t src = ok ? (gptr_t)(p.src + (grow * p.Cs + cch * CK + ls * 8)) : zero;
@@ -232,11 +251,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NB];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     VC_STAMP(1);
 
     const int nchunks = p.Cs / CK;
@@ -251,24 +270,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int WPT = (Cfg::WPIECES + NW - 1) / NW;  // weight DMA instructions per wave per tap
     static_assert(Cfg::WPIECES % NW == 0 || Cfg::WPIECES < NW, "every wave must issue the same number of weight pieces");
 
-    // fragments of one tap: 2 k-steps x (4 weight + 4 activation) ds_read_b128
-    auto load_frags = [&](int tap, bf16x8 (&fa)[KS][4], bf16x8 (&fb)[KS][4]) {
+    // fragments of one tap: KS k-steps x (4 weight + NB activation) ds_read_b128
+    auto load_frags = [&](int tap, bf16x8 (&fa)[KS][4], bf16x8 (&fb)[KS][NB]) {
         const char* sW = smem + (tap % NWB) * WBUF;
         const int shift = __builtin_amdgcn_readlane(tv_shift, tap);  // row shift of this tap inside the image
-        unsigned baddr[KS][4];
+        unsigned baddr[KS][NB];
         if constexpr (PAD) {
-            // byte offset of the row L = (row << 7); its 16-byte slot is lg ^ ((row >> 1) & 7) (+4 for k-step 1)
-            const unsigned sh = (unsigned)shift << 7;
+            // byte offset of the row L = (row << RSH); its 16-byte slot is lg ^ swz(row) (+4 for k-step 1):
+            // 128-byte rows: swz = (row >> 1) & 7 = (L >> 8) & 7;  64-byte rows: swz = (row >> 2) & 3 = (L >> 8) & 3
+            const unsigned sh = (unsigned)shift << RSH;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 const unsigned L = (unsigned)lrow0[b] + sh;
-                const unsigned sw = (L >> 4) & 0x70u;
+                const unsigned sw = (L >> 4) & (CK == 64 ? 0x70u : 0x30u);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) baddr[ks][b] = halo_base + ((sw ^ (unsigned)((lg << 4) ^ (ks << 6))) + L);
             }
         } else {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 const int lrow = lrow0[b] + shift;
                 const unsigned a_in = halo_base + (unsigned)lrow * ROWB + ((unsigned)(lg ^ Cfg::swz(lrow)) << 4);
                 const unsigned a_zero = ZERO_OFF + ((unsigned)lg << 4);
@@ -286,17 +306,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             if (!(VC_HALO_ABLATE & 2)) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) fb[ks][b] = *(const bf16x8*)(smem + baddr[ks][b]);
+                for (int b = 0; b < NB; ++b) fb[ks][b] = *(const bf16x8*)(smem + baddr[ks][b]);
             }
         }
     };
-    auto mfma_all = [&](const bf16x8 (&fa)[KS][4], const bf16x8 (&fb)[KS][4]) {
+    auto mfma_all = [&](const bf16x8 (&fa)[KS][4], const bf16x8 (&fb)[KS][NB]) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     if (VC_HALO_ABLATE & 16) {
                         asm volatile("" : "+v"(acc[a][b]) : "v"(fa[ks][a]), "v"(fb[ks][b]));
                     } else {
@@ -342,16 +362,63 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // tap t+1 into `nfa/nfb` WHILE the MFMAs of tap t run from `cfa/cfb`.  The reads are interleaved with
     // the MFMAs in program order (2 ds_read_b128 per 4 MFMAs): issued all up front, the 16 reads would
     // overflow the 4-bit lgkmcnt and the compiler would have to drain them before the first MFMA.
-    auto stage = [&](int t, int cch, bf16x8 (&cfa)[KS][4], bf16x8 (&cfb)[KS][4], bf16x8 (&nfa)[KS][4],
-                     bf16x8 (&nfb)[KS][4]) {
+    auto stage = [&](int t, int cch, bf16x8 (&cfa)[KS][4], bf16x8 (&cfb)[KS][NB], bf16x8 (&nfa)[KS][4],
+                     bf16x8 (&nfb)[KS][NB]) {
         wait_w(t + 2 < p.ntaps ? 1 : 0);  // issued so far: up to W[t+2]
         if (!(VC_HALO_ABLATE & 8) && t + 3 < p.ntaps) issue_w(t + 3, cch, (t + 3) % NWB);  // overwrites W[t]: its reads are retired
         load_frags(t + 1, nfa, nfb);
         mfma_all(cfa, cfb);
+        if constexpr (NB == 4) {
 #pragma unroll
-        for (int i = 0; i < 4 * KS; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMAs
+            for (int i = 0; i < 4 * KS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMAs
+            }
+        } else {
+            HaloSched<0, (4 + NB) * KS, 4 * NB * KS>::run();
+        }
+    };
+
+    // NB > 4 (two workgroups per CU, KS == 1): 112-128 accumulator registers leave no room for two full fragment
+    // sets.  The MFMAs run position block by position block (b outer, the four co blocks inner), so the activation
+    // fragment of block b is dead after its four MFMAs and the same registers take tap t+1's fragment of block b
+    // right there: ONE activation set refreshed in place, only the four weight fragments are double-buffered.
+    auto stage2 = [&](int t, int cch, bf16x8 (&cfa)[KS][4], bf16x8 (&nfa)[KS][4], bf16x8 (&fb)[KS][NB]) {
+        wait_w(t + 2 < p.ntaps ? 1 : 0);
+        if (!(VC_HALO_ABLATE & 8) && t + 3 < p.ntaps) issue_w(t + 3, cch, (t + 3) % NWB);
+        const char* sW = smem + ((t + 1) % NWB) * WBUF;
+        const int shift = __builtin_amdgcn_readlane(tv_shift, t + 1);
+        unsigned baddr[NB];
+        if constexpr (PAD) {
+            const unsigned sh = (unsigned)shift << RSH;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const unsigned L = (unsigned)lrow0[b] + sh;
+                const unsigned sw = (L >> 4) & (CK == 64 ? 0x70u : 0x30u);
+                baddr[b] = halo_base + ((sw ^ (unsigned)(lg << 4)) + L);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int lrow = lrow0[b] + shift;
+                const unsigned a_in = halo_base + (unsigned)lrow * ROWB + ((unsigned)(lg ^ Cfg::swz(lrow)) << 4);
+                const unsigned a_zero = ZERO_OFF + ((unsigned)lg << 4);
+                baddr[b] = ((mask[b] >> (t + 1)) & 1u) ? a_in : a_zero;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) nfa[0][a] = *(const bf16x8*)(sW + (a * 16 + l15) * ROWB + ((lg ^ aswz) << 4));
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cfa[0][a], fb[0][b], acc[a][b], 0, 0, 0);
+            fb[0][b] = *(const bf16x8*)(smem + baddr[b]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the four weight fragments of tap t+1
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // block b of tap t
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // its registers take block b of tap t+1
         }
     };
 
@@ -361,32 +428,48 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         issue_w(0, cch, 0);
         if (p.ntaps > 1) issue_w(1, cch, 1);
         if (p.ntaps > 2) issue_w(2, cch, 2);
-        VC_STAMP(2);
+        if (cch == cbeg) VC_STAMP(2);
         wait_w(p.ntaps > 2 ? 2 : (p.ntaps > 1 ? 1 : 0));
-        VC_STAMP(3);
-        bf16x8 fa0[KS][4], fb0[KS][4], fa1[KS][4], fb1[KS][4];
-        load_frags(0, fa0, fb0);
-        int tap = 0;
-        for (; tap + 2 < p.ntaps; tap += 2) {
-            stage(tap, cch, fa0, fb0, fa1, fb1);
-            stage(tap + 1, cch, fa1, fb1, fa0, fb0);
-        }
-        if (tap + 1 < p.ntaps) {
-            stage(tap, cch, fa0, fb0, fa1, fb1);
-            mfma_all(fa1, fb1);
+        VC_STAMP(cch == cbeg ? 3 : 5);
+        if constexpr (NB == 4) {
+            bf16x8 fa0[KS][4], fb0[KS][NB], fa1[KS][4], fb1[KS][NB];
+            load_frags(0, fa0, fb0);
+            int tap = 0;
+            for (; tap + 2 < p.ntaps; tap += 2) {
+                stage(tap, cch, fa0, fb0, fa1, fb1);
+                stage(tap + 1, cch, fa1, fb1, fa0, fb0);
+            }
+            if (tap + 1 < p.ntaps) {
+                stage(tap, cch, fa0, fb0, fa1, fb1);
+                mfma_all(fa1, fb1);
+            } else {
+                mfma_all(fa0, fb0);
+            }
         } else {
-            mfma_all(fa0, fb0);
+            static_assert(NB == 4 || KS == 1, "the in-place fragment refresh is written for one k-step per tap");
+            bf16x8 fa0[KS][4], fa1[KS][4], fb[KS][NB];
+            load_frags(0, fa0, fb);
+            int tap = 0;
+            for (; tap + 2 < p.ntaps; tap += 2) {
+                stage2(tap, cch, fa0, fa1, fb);
+                stage2(tap + 1, cch, fa1, fa0, fb);
+            }
+            if (tap + 1 < p.ntaps) {
+                stage2(tap, cch, fa0, fa1, fb);
+                mfma_all(fa1, fb);
+            } else {
+                mfma_all(fa0, fb);
+            }
         }
-        VC_STAMP(4);
+        VC_STAMP(cch == cbeg ? 4 : 6);
     }
 
-    // ---- epilogue: acc[a][b][j] = D[co = co0 + a*16 + lg*4 + j][slot = wave*64 + b*16 + l15]
-    VC_STAMP(5);
+    // ---- epilogue: acc[a][b][j] = D[co = co0 + a*16 + lg*4 + j][slot = wave*WS + b*16 + l15]
     const int cobase = co0 + lg * 4;
     if (p.partial != nullptr) {
         float* slab = p.partial + (size_t)blockIdx.z * p.partial_stride;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < NB; ++b) {
             if (ooff[b] < 0) continue;
 #pragma unroll
             for (int a = 0; a < 4; ++a) *(f32x4*)(slab + (size_t)ooff[b] + cobase + a * 16) = acc[a][b];
@@ -401,7 +484,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const f32x4 s4 = *(const f32x4*)(p.ep_params + 2 * p.Cn + cobase + a * 16);
             const f32x4 h4 = *(const f32x4*)(p.ep_params + 3 * p.Cn + cobase + a * 16);
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = acc[a][b][j] * s4[j] + h4[j];
@@ -411,23 +494,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     }
     __syncthreads();  // every wave has left the tap loop: the image area is free
-    // The image area is reused: [NW][64 positions][64 co] bf16 with a 144-byte row pitch for the output
+    // The image area is reused: [NW][WS positions][64 co] bf16 with a 144-byte row pitch for the output
     // tile (so that it leaves as whole 128-byte channels-last rows, 16 bytes per lane), then
     // [NW][2][64] floats for the BatchNorm partial sums of the waves.
     constexpr int OPITCH = 144;
-    char* otile = smem + HALO_OFF + wave * 64 * OPITCH;
-    float* sstat = (float*)(smem + HALO_OFF + NW * 64 * OPITCH);
-    int* sooff = (int*)(sstat + NW * 128);  // [NW][64] output offsets of the wave's slots
+    char* otile = smem + HALO_OFF + wave * WS * OPITCH;
+    float* sstat = (float*)(smem + HALO_OFF + NW * WS * OPITCH);
+    int* sooff = (int*)(sstat + NW * 128);  // [NW][WS] output offsets of the wave's slots
     if (!p.accumulate) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const f32x4 v = acc[a][b];
                 *(bf16x4*)(otile + (b * 16 + l15) * OPITCH + (a * 16 + lg * 4) * 2) =
                     (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
             }
-            if (lg == 0) sooff[wave * 64 + b * 16 + l15] = ooff[b];
+            if (lg == 0) sooff[wave * WS + b * 16 + l15] = ooff[b];
         }
     }
     if (p.stats != nullptr) {
@@ -437,7 +520,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int j = 0; j < 4; ++j) {
                 float ss = 0.f, qq = 0.f;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     const float v = ooff[b] >= 0 ? acc[a][b][j] : 0.f;
                     ss += v;
                     qq += v * v;
@@ -460,11 +543,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         atomicAdd(srep + (tid < 64 ? 0 : p.Cn) + co0 + (tid & 63), s);
     }
     if (!p.accumulate) {
-        // each wave streams its own 64 x 64 tile: 8 rows of 128 bytes per instruction
+        // each wave streams its own WS x 64 tile: 8 rows of 128 bytes per instruction
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NB * 2; ++i) {
             const int r = i * 8 + (lane >> 3);
-            const int oo = sooff[wave * 64 + r];
+            const int oo = sooff[wave * WS + r];
             if (oo >= 0) {
                 bf16x8 v = *(const bf16x8*)(otile + r * OPITCH + (lane & 7) * 16);
                 if (p.ep_res != nullptr) {
@@ -483,7 +566,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     } else {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < NB; ++b) {
             if (ooff[b] < 0) continue;
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
@@ -498,35 +581,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         }
     }
-    VC_STAMP(6);
+    VC_STAMP(7);
     vc_bn_fin_last(p.fin, p.stats, p.Cn);
 }
 
 // LDS bytes of a workgroup: ring + zero row + the larger of the image and the epilogue staging area
-template <int NW, int CK>
-constexpr int halo_lds_bytes(int npieces) {
-    const int img = HaloCfg<CK>::HALO_OFF + npieces * 1024;
-    const int epi = HaloCfg<CK>::HALO_OFF + NW * 64 * 144 + NW * 128 * 4 + NW * 64 * 4;
+static int halo_lds(int NW, int CK, int npieces, int NB = 4) {
+    const int off = CK == 32 ? HaloCfg<32>::HALO_OFF : HaloCfg<64>::HALO_OFF;
+    const int img = off + npieces * 1024;
+    const int epi = off + NW * NB * 16 * 144 + NW * 128 * 4 + NW * NB * 16 * 4;
     return img > epi ? img : epi;
 }
-static int halo_lds(int NW, int CK, int npieces) {
-    if (CK == 32) return NW == 8 ? halo_lds_bytes<8, 32>(npieces) : halo_lds_bytes<4, 32>(npieces);
-    return NW == 8 ? halo_lds_bytes<8, 64>(npieces) : halo_lds_bytes<4, 64>(npieces);
-}
 
-template <int NW, int CK, bool PAD>
+template <int NW, int CK, bool PAD, int NB = 4>
 int launch_halo(const VcHaloParams& p, hipStream_t stream) {
-    const int lds = halo_lds_bytes<NW, CK>(p.npieces);
+    const int lds = halo_lds(NW, CK, p.npieces, NB);
     static bool attr_set[64] = {false};  // per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)halo_conv_kernel<NW, CK, PAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)halo_conv_kernel<NW, CK, PAD, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set[dev] = true;
     }
     dim3 grid(p.ntg * p.nseg, p.Cn / 64, p.splits > 1 ? p.splits : 1);
     (void)hipGetLastError();
-    hipLaunchKernelGGL((halo_conv_kernel<NW, CK, PAD>), grid, dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((halo_conv_kernel<NW, CK, PAD, NB>), grid, dim3(NW * 64), lds, stream, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         vc_set_error("halo conv launch failed: %s", hipGetErrorString(e));
@@ -549,18 +628,29 @@ static const double vc_halo_kpad = getenv("VC_HALO_KPAD") ? atof(getenv("VC_HALO
 
 int vc_halo_plan(int NP, int T, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* plan) {
     const int HW = H * W;
-    const char* env = getenv("VC_HALO_FORCE");  // "NW,TT,SEG,splits[,CK[,pad]]" for experiments
+    const char* env = getenv("VC_HALO_FORCE");  // "NW,TT,SEG,splits[,CK[,pad[,NB]]]" for experiments
     static const bool no_pad = getenv("VC_HALO_NO_PAD") != nullptr;
+    // Measured on MI355X (layer1, 64 x 8x28x28 x 64 -> 64, scripts/halo_stamps.py): the two-workgroup form runs its tap
+    // steps at 1100 clocks per 28 MFMAs x 2 workgroups (83 % of the shared pipe) but LDS-DMA of 64-byte rows moves
+    // 4-6 B/clk/CU against 11 for 128-byte rows, so fill + epilogue grow from 19k to 54k clocks per tile and the
+    // kernel ties the one-workgroup form (0.129 ms both).  Kept for experiments: VC_HALO_2WG=1 lets the planner pick it.
+    static const bool no_2wg = getenv("VC_HALO_2WG") == nullptr;
+    static const double k2wg = getenv("VC_HALO_K2WG") ? atof(getenv("VC_HALO_K2WG")) : 1.15;
     double best = 1e30;
     VcHaloPlan bp;
     bp.NW = 0;
-    // the planner only proposes 64-channel chunks: the 32-channel two-workgroup form measured no faster
-    // (its doubled weight traffic stalls the LDS-DMA issue) and stays reachable through VC_HALO_FORCE
-    const int CK = 64;
-    const int nchunks = Cs / CK;
-    for (int pad = 0; pad <= (no_pad ? 0 : 1); ++pad) {
-        for (int NW = 4; NW <= 8; NW += 4) {
-            const int BM = NW * 64;
+    // forms: one workgroup per CU (8 or 4 waves of 64 x 64, 64-channel chunks), or two per CU (4 waves of 64 x NB*16,
+    // 32-channel chunks: half the image bytes per chunk).  A 32-channel form with 64 x 64 wave tiles measured no
+    // faster (doubled weight traffic per MFMA) and stays reachable through VC_HALO_FORCE only.
+    struct Form { int NW, NB, CK; };
+    static const Form forms[] = {{4, 4, 64}, {8, 4, 64}, {4, 7, 32}};
+    for (const Form& f : forms) {
+        if (f.CK == 32 && no_2wg) continue;
+        const int CK = f.CK, NW = f.NW, NB = f.NB;
+        const int nchunks = Cs / CK;
+        const int PR = CK == 32 ? 16 : 8;
+        for (int pad = 0; pad <= (no_pad ? 0 : 1); ++pad) {
+            const int BM = NW * NB * 16;
             for (int SEG = 1; SEG <= (HW < BM ? HW : BM); ++SEG) {
                 // segments that are whole (h) rows, whole planes, or an even split of a plane
                 if (!(SEG == HW || SEG % W == 0 || HW % SEG == 0)) continue;
@@ -572,44 +662,55 @@ int vc_halo_plan(int NP, int T, int H, int W, int Cs, int Cn, int ntaps, VcHaloP
                     while (TT > 1 && T % TT != 0) --TT;  // a tile must not straddle two samples
                 }
                 if (TT < 1) continue;
-                const int HR = pad ? (SEG / W + 2) * (W + 2) : SEG + 2 * W + 2;
+                const int HR = pad ? (SEG / W + 2) * (W + 1) + 1 : SEG + 2 * W + 2;
                 const int rows = (TT + 2) * HR;
-                const int PR = 8;
                 const int npieces = (rows + PR - 1) / PR;
-                const int lds = halo_lds(NW, CK, npieces);
+                const int lds = halo_lds(NW, CK, npieces, NB);
                 if (lds > 160 * 1024) continue;
+                if (CK == 32 && 2 * lds > 160 * 1024) continue;  // the 32-channel forms exist for two workgroups per CU
                 const int wgcu = (NW == 4 && 2 * lds <= 160 * 1024) ? 2 : 1;
                 const long tiles = (long)((NP + TT - 1) / TT) * ((HW + SEG - 1) / SEG);
                 for (int splits = 1; splits <= nchunks; splits *= 2) {
                     const int cps = (nchunks + splits - 1) / splits;
                     const long wgs = tiles * (Cn / 64) * splits;
                     const long rounds = (wgs + 256L * wgcu - 1) / (256L * wgcu);
-                    double per_tap = NW == 8 ? 1550.0 : (wgcu == 2 ? 1700.0 : 2500.0);
-                    if (pad) per_tap *= vc_halo_kpad / 1550.0;
-                    const double fill = 11.5 * rows;
-                    const double t_wg = 2000.0 + 7000.0 + cps * (fill + ntaps * per_tap);
+                    double per_tap, fill, fixed;
+                    if (CK == 32) {
+                        // two workgroups share the CU's MFMA pipes: a tap step of one takes about twice its own MFMA
+                        // time (NB*4 MFMAs of 16 clocks); the partner's MFMAs cover this one's fill and epilogue
+                        per_tap = k2wg * 2.0 * NB * 4 * 16;
+                        fill = 6.0 * rows;
+                        fixed = 2000.0 + 4000.0;
+                    } else {
+                        per_tap = NW == 8 ? 1550.0 : (wgcu == 2 ? 1700.0 : 2500.0);
+                        if (pad) per_tap *= vc_halo_kpad / 1550.0;
+                        fill = 11.5 * rows;
+                        fixed = 2000.0 + 7000.0;
+                    }
+                    const double t_wg = fixed + cps * (fill + ntaps * per_tap);
                     double cost = rounds * t_wg;
                     if (splits > 1) cost += 15000.0 + 2.4e3 * ((double)NP * HW * Cn * 4.0 * (splits + 0.5)) / 4.0e6;
                     if (cost < best) {
                         best = cost;
-                        bp.NW = NW, bp.TT = TT, bp.SEG = SEG, bp.splits = splits, bp.CK = CK, bp.pad = pad;
+                        bp.NW = NW, bp.TT = TT, bp.SEG = SEG, bp.splits = splits, bp.CK = CK, bp.pad = pad, bp.NB = NB;
                     }
                 }
             }
         }
     }
     if (env) {
-        int a, b, c, d, e = 64, f = 0;
-        const int nf = sscanf(env, "%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e, &f);
-        if (nf >= 4 && (a == 4 || a == 8) && b >= 1 && c >= 1 && d >= 1 && b * c <= a * 64 && (e == 64 || e == 32) &&
-            d <= Cs / e && (f == 0 || (e == 64 && c % W == 0 && HW % c == 0 && T % b == 0)))
-            bp.NW = a, bp.TT = b, bp.SEG = c, bp.splits = d, bp.CK = e, bp.pad = f;
+        int a, b, c, d, e = 64, f = 0, g = 4;
+        const int nf = sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &a, &b, &c, &d, &e, &f, &g);
+        if (nf >= 4 && (a == 4 || a == 8) && b >= 1 && c >= 1 && d >= 1 && (g == 4 || (a == 4 && e == 32 && g == 7)) &&
+            b * c <= a * g * 16 && (e == 64 || (e == 32 && a == 4)) && d <= Cs / e &&
+            (f == 0 || (c % W == 0 && HW % c == 0 && T % b == 0 && (e == 64 || g != 4))))
+            bp.NW = a, bp.TT = b, bp.SEG = c, bp.splits = d, bp.CK = e, bp.pad = f, bp.NB = g;
     }
     if (bp.NW == 0) return -1;
     static const bool verbose = getenv("VC_HALO_VERBOSE") != nullptr;
     if (verbose)
-        fprintf(stderr, "halo plan NP=%d T=%d H=%d W=%d Cs=%d Cn=%d taps=%d -> NW=%d TT=%d SEG=%d splits=%d CK=%d pad=%d\n", NP, T, H,
-                W, Cs, Cn, ntaps, bp.NW, bp.TT, bp.SEG, bp.splits, bp.CK, bp.pad);
+        fprintf(stderr, "halo plan NP=%d T=%d H=%d W=%d Cs=%d Cn=%d taps=%d -> NW=%d NB=%d TT=%d SEG=%d splits=%d CK=%d pad=%d\n", NP, T,
+                H, W, Cs, Cn, ntaps, bp.NW, bp.NB, bp.TT, bp.SEG, bp.splits, bp.CK, bp.pad);
     *plan = bp;
     return 0;
 }
@@ -626,12 +727,12 @@ int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream) 
     const int HW = p.H * p.W;
     p.TT = plan.TT, p.SEG = plan.SEG;
     p.pad = plan.pad;
-    p.R = p.SEG / p.W, p.Wp = p.W + 2;
-    if (p.pad && (plan.CK != 64 || p.SEG % p.W != 0 || HW % p.SEG != 0 || p.T % p.TT != 0)) {
+    p.R = p.SEG / p.W, p.Wp = p.W + 1;
+    if (p.pad && ((plan.CK != 64 && plan.NB == 4) || p.SEG % p.W != 0 || HW % p.SEG != 0 || p.T % p.TT != 0)) {
         vc_set_error("halo conv: padded form needs whole-row segments and TT | T (TT=%d SEG=%d)", p.TT, p.SEG);
         return -2;
     }
-    p.HR = p.pad ? (p.R + 2) * p.Wp : p.SEG + 2 * p.W + 2;
+    p.HR = p.pad ? (p.R + 2) * p.Wp + 1 : p.SEG + 2 * p.W + 2;
     p.dHR = vc_make_fastdiv(p.HR), p.dWp = vc_make_fastdiv(p.Wp);
     p.halo_rows = (p.TT + 2) * p.HR;
     const int PR = plan.CK == 32 ? 16 : 8;
@@ -649,8 +750,9 @@ int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream) 
     }
     p.ntg = (p.NP + p.TT - 1) / p.TT;
     p.nseg = (HW + p.SEG - 1) / p.SEG;
-    if (p.TT * p.SEG > plan.NW * 64 || halo_lds(plan.NW, plan.CK, p.npieces) > 160 * 1024 || (plan.CK != 32 && plan.CK != 64) ||
-        (plan.CK == 32 && plan.NW != 4)) {
+    if (p.TT * p.SEG > plan.NW * plan.NB * 16 || halo_lds(plan.NW, plan.CK, p.npieces, plan.NB) > 160 * 1024 ||
+        (plan.CK != 32 && plan.CK != 64) || (plan.CK == 32 && plan.NW != 4) ||
+        !(plan.NB == 4 || (plan.CK == 32 && plan.NB == 7))) {
         vc_set_error("halo conv: plan does not fit (TT=%d SEG=%d NW=%d)", p.TT, p.SEG, plan.NW);
         return -2;
     }
@@ -662,7 +764,10 @@ int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream) 
         }
         p.taps[i].src_off = t.ot * p.HR + t.oh * (p.pad ? p.Wp : p.W) + t.ow;
     }
-    if (plan.CK == 32) return launch_halo<4, 32, false>(p, stream);
-    if (p.pad) return plan.NW == 8 ? launch_halo<8, 64, true>(p, stream) : launch_halo<4, 64, true>(p, stream);
-    return plan.NW == 8 ? launch_halo<8, 64, false>(p, stream) : launch_halo<4, 64, false>(p, stream);
+    if (plan.CK == 32) {
+        if (plan.NB == 7) return p.pad ? launch_halo<4, 32, true, 7>(p, stream) : launch_halo<4, 32, false, 7>(p, stream);
+        return launch_halo<4, 32, false, 4>(p, stream);
+    }
+    if (p.pad) return plan.NW == 8 ? launch_halo<8, 64, true, 4>(p, stream) : launch_halo<4, 64, true, 4>(p, stream);
+    return plan.NW == 8 ? launch_halo<8, 64, false, 4>(p, stream) : launch_halo<4, 64, false, 4>(p, stream);
 }

@@ -79,6 +79,7 @@ struct VcHaloParams {
 struct VcHaloPlan {
     int NW, TT, SEG, splits, CK;  // CK: channels per K chunk (64, or 32 for two workgroups per CU)
     int pad;                      // zero-padded LDS image (no per-tap validity selects)
+    int NB;                       // 16-position blocks per wave (4; 7 or 8 in the two-workgroups-per-CU forms)
 };
 int vc_halo_plan(int NP, int T, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* plan);
 int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream);
