@@ -44,9 +44,11 @@ GFLOP_PER_CLIP = {(18, 16, 112): 43.25, (50, 16, 112): 53.81}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", type=int, default=18, help="ResNet depth (18 = config 2, 50 = config 3)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", type=int, default=None,
+                    help="ResNet depth; default: 18 on one GPU (BASELINE config 2), 50 on several (config 3, the "
+                         "data-parallel headline)")
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--clip-len", type=int, default=16)
     ap.add_argument("--crop", type=int, default=112)
@@ -109,6 +111,63 @@ def pmc_traffic(key):
         return None
 
 
+def pointwise_bytes(key):
+    """algorithmic HBM bytes of a 1x1x1 conv launch: the activation read once and the result written once, bf16
+    (bandwidth kernels are priced at (elements read + elements written) x 2 B); weights are noise."""
+    kind, N, Ci, T, H, W, Co, kt, kh, kw, st, sh, sw = key
+    To, Ho, Wo = (T - 1) // st + 1, (H - 1) // sh + 1, (W - 1) // sw + 1
+    m_in = N * To * Ho * Wo if kind != "dgrad" else N * T * H * W  # a strided 1x1x1 forward only reads the rows it keeps
+    return 2.0 * (m_in * Ci + N * To * Ho * Wo * Co) if kind != "wgrad" else 2.0 * N * To * Ho * Wo * (Ci + Co)
+
+
+def launch_roofline(key, ms, flops):
+    """roofline object of one conv launch: the 1x1x1 convs of the Bottleneck (K = 64..2048 per output row) are bound
+    by HBM bandwidth, everything else by the MFMA pipe."""
+    name = "conv3d %s %s" % (key[0], "x".join(str(v) for v in key[1:]))
+    if len(key) == 13 and key[7] * key[8] * key[9] == 1:
+        gbs = pointwise_bytes(key) / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(gbs / PEAK_HBM_GBS, 4), "kernel": name}
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "kernel": name}
+
+
+def family_rooflines(table):
+    """conv launches of one step grouped by the kernel that serves them; returns the family with the largest share."""
+    fam = {}
+    for key, (n, ms, fl) in table.items():
+        if key[0] in ("stem_fwd", "stem_wgrad"):
+            name = key[0] + "_kernel"
+        else:
+            kind, k, s = key[0], key[7] * key[8] * key[9], key[10] * key[11] * key[12]
+            if k == 27 and s == 1:
+                name = "wgrad9_kernel (3x3x3 stride-1 wgrad)" if kind == "wgrad" else "halo_conv_kernel (3x3x3 stride-1 fwd+dgrad)"
+            elif k == 1:
+                name = "1x1x1 convs (igemm_kernel / wgrad_kernel, HBM-bound)"
+            else:
+                name = "strided convs (igemm_kernel / wgrad_kernel)"
+        f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
+        f[0] += n
+        f[1] += n * ms
+        f[2] += n * fl
+        f[3] += n * (pointwise_bytes(key) if len(key) == 13 and key[7] * key[8] * key[9] == 1 else 0.0)
+    if not fam:
+        return None
+    tot = sum(f[1] for f in fam.values())
+    name, (n, ms, fl, by) = max(fam.items(), key=lambda kv: kv[1][1])
+    out = {"kernel": name, "launches_per_step": n, "ms_per_step": round(ms, 4), "share_of_conv_time": round(ms / tot, 4)}
+    if by > 0:
+        gbs = by / (ms * 1e-3) / 1e9
+        out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4)})
+    else:
+        ach = fl / (ms * 1e-3) / 1e12
+        out.update({"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4)})
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,6 +182,8 @@ def main():
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    if args.model is None:
+        args.model = 18 if world == 1 else 50
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -184,6 +245,7 @@ def main():
     table = ops.TIMER.summary()
     ops.TIMER = None
     dominant = max(table, key=lambda k: table[k][0] * table[k][1]) if table else None
+    by_time = family_rooflines(table)
     if args.profile_kernels and rank == 0:
         tot = sum(v[0] * v[1] for v in table.values())
         for k, (n, ms, fl) in sorted(table.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
@@ -213,11 +275,9 @@ def main():
         ops.TIMER = None
         if dominant in summ:
             n, ms, fl = summ[dominant]
-            ach = fl / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dominant),
-                    "kernel": "conv3d %s %s" % (dominant[0], "x".join(str(v) for v in dominant[1:])),
-                    "launches_timed": n, "avg_ms": round(ms, 4), "flops_per_launch": fl}
+            roof = launch_roofline(dominant, ms, fl)
+            roof.update({"traffic": pmc_traffic(dominant), "launches_timed": n, "avg_ms": round(ms, 4),
+                         "flops_per_launch": fl})
 
     if rank == 0:
         clips = args.batch * world * args.steps
@@ -235,6 +295,9 @@ def main():
                                                      args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": roof,
+            # the kernel FAMILY with the largest aggregate share of the step's conv time (one warm-up step with every
+            # launch on one stream, so the event-bracketed times are exclusive), beside the single dominant launch above
+            "roofline_by_time": by_time,
         }
         if gf is not None and not args.eval:
             out["mfma_frac_end_to_end"] = round(value * gf / 1e3 / PEAK_BF16_TFLOPS, 4)

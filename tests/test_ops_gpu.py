@@ -513,3 +513,46 @@ def test_conv3d_fwd_inference_epilogue(case):
     z_r = ops.conv3d_fwd(d, xd, wf, act_params=prm, relu=True, residual=to_nthwc_dev(res))
     torch.cuda.synchronize()
     assert rel_l2(from_nthwc(z_r), ref_r) <= TOL_BF16
+
+
+def test_concurrent_host_threads_on_distinct_streams():
+    """include/vc3d.h: calls from distinct host threads on distinct streams are safe.  The per-device set-up of a kernel
+    (raising its dynamic-LDS limit) used to sit behind a plain static flag; it is a std::call_once now.  Four threads
+    launch the halo conv (the kernel with the largest LDS request) at the same time, each on its own stream with its
+    own workspace, first call in this process for two of the geometries; every result equals the single-threaded one."""
+    import threading
+    from vc3d import capi, ops
+    geoms = [(4, 64, 4, 12, 12, 64), (2, 128, 2, 10, 10, 128), (4, 64, 3, 9, 11, 128), (2, 128, 4, 6, 6, 64)]
+    cases = []
+    for i, (N, Ci, T, H, W, Co) in enumerate(geoms):
+        d = ops.conv_desc(N, Ci, T, H, W, Co, 3, 1, 1)
+        g = torch.Generator(device="cuda").manual_seed(40 + i)
+        x = torch.randn(N, T, H, W, Ci, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(Co, 27 * Ci, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+        need = int(capi.lib.vc_conv3d_workspace_bytes(d, 0))
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+        y = torch.empty(N, T, H, W, Co, dtype=torch.bfloat16, device="cuda")
+        cases.append((d, x, w, ws, need, y, torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(c):
+        d, x, w, ws, need, y, st = c
+        for _ in range(20):
+            rc = capi.lib.vc_conv3d_fwd(d, x.data_ptr(), w.data_ptr(), y.data_ptr(), None, ws.data_ptr() if need else None,
+                                        need, st.cuda_stream)
+            if rc != 0:
+                errs.append(capi.lib.vc_last_error().decode())
+                return
+
+    threads = [threading.Thread(target=work, args=(c,)) for c in cases]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for d, x, w, ws, need, y, st in cases:
+        ref = ops.conv3d_fwd(d, x, w)
+        torch.cuda.synchronize()
+        assert torch.equal(ref.view(torch.int16), y.view(torch.int16))

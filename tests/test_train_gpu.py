@@ -239,3 +239,76 @@ def test_training_trajectory_tracks_the_fp32_oracle():
         assert abs(a - b) <= 0.05 * b + 0.05
     assert lr_[-1] < 0.5 * lr_[0], "the oracle itself was expected to fit the batch"
     assert lp[-1] <= 1.5 * lr_[-1] + 0.1
+
+
+def test_validate_top5_and_test_step_clips():
+    """validate() keeps returning top-1 (its caller compares it, reference train.py:87-89), reports top-5 in
+    validate.last, and honours TEST.TEST_STEP: a raw uint8 video is scored on TEST_STEP uniformly spaced clips whose
+    logits are averaged (reference function.py:129-146: inner steps feeding a Score_Updater)."""
+    from core.function import validate
+    from core.loss import Loss
+    from models.model import create_model
+    from utils.utils import ChooseInput
+    from core.config import config as gcfg
+    cfg = make_config(18, 9)
+    cfg.MODEL.CLIP_LEN, cfg.MODEL.CROP_SIZE, cfg.MODEL.FRAME_STEP = 4, 32, 1
+    cfg.TEST.TEST_STEP, cfg.TEST.PRINT_EVERY = 3, 100
+    keep = (gcfg.MODEL.CLIP_LEN, gcfg.MODEL.CROP_SIZE, gcfg.MODEL.FRAME_STEP)
+    gcfg.MODEL.CLIP_LEN, gcfg.MODEL.CROP_SIZE, gcfg.MODEL.FRAME_STEP = 4, 32, 1  # ChooseInput reads the global config
+    try:
+        torch.manual_seed(2)
+        model = create_model(cfg, False).cuda().eval()
+        g = torch.Generator().manual_seed(9)
+        frames = torch.randint(0, 256, (5, 12, 36, 40, 3), generator=g, dtype=torch.uint8)
+        with torch.no_grad():
+            lo = torch.stack([model(ChooseInput(frames.cuda(), None, k, 3))[1].float() for k in range(3)]).mean(0)
+        top5 = lo.topk(5, dim=1).indices.cpu()
+        # labels: video 0 -> its top-1, video 1 -> its 3rd choice, video 2 -> its 5th, video 3 -> its 6th, video 4 -> top-1
+        order = lo.argsort(dim=1, descending=True).cpu()
+        target = torch.tensor([order[0, 0], order[1, 2], order[2, 4], order[3, 5], order[4, 0]])
+        acc = validate(cfg, [(frames, target)], model, Loss(cfg), 0)
+        assert abs(acc - 2 / 5) < 1e-9
+        assert abs(validate.last["top5"] - 4 / 5) < 1e-9 and validate.last["count"] == 5
+        # the three clips differ (t0 = 0, 4, 8 of 12 frames): a single centre clip gives other logits
+        with torch.no_grad():
+            single = model(ChooseInput(frames.cuda(), None))[1].float()
+        assert float((single - lo).abs().max()) > 1e-3
+        assert top5.shape == (5, 5)
+    finally:
+        gcfg.MODEL.CLIP_LEN, gcfg.MODEL.CROP_SIZE, gcfg.MODEL.FRAME_STEP = keep
+
+
+def test_resume_restores_optimizer_scheduler_and_epoch(tmp_path, monkeypatch):
+    """train.py writes checkpoint.pth every epoch (model, FlatSGD momentum, MultiStepLR, epoch, best accuracy;
+    reference config.py:53 BEGIN_EPOCH, train.py:79-91).  Two epochs in one run == one epoch, stop, resume for the
+    second: same final weights (the synthetic loaders are deterministic per epoch), to the run-to-run noise of the
+    BatchNorm atomics (rel-L2 <= 2e-3 on this tiny net; a lost momentum buffer or a restarted LR schedule moves the
+    weights by percents)."""
+    monkeypatch.syspath_prepend(PKG)
+    monkeypatch.chdir(tmp_path)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    import logging
+    import train as train_mod
+    from helpers import rel_l2
+    common = ["MODEL.INIT_WEIGHTS=false", "MODEL.CLFDIM=5", "MODEL.CLIP_LEN=4", "MODEL.CROP_SIZE=32", "TRAIN.PRINT_EVERY=100",
+              "TEST.PRINT_EVERY=100", "TRAIN.BATCH_SIZE=4", "TEST.BATCH_SIZE=4", "TRAIN.TRAIN_STEP=1", "TRAIN.OPTIMIZER=sgd",
+              "TRAIN.LR=0.05", "TRAIN.LR_MILESTONES=1", "TRAIN.LR_DECAY_RATE=0.1", "TRAIN.SHUFFLE=false"]
+    torch.manual_seed(0)
+    train_mod.main(common + ["OUTPUT_DIR=%s" % (tmp_path / "a"), "TRAIN.END_EPOCH=2"])
+    full = torch.load(tmp_path / "a" / "checkpoint.pth", map_location="cpu", weights_only=True)
+    torch.manual_seed(0)
+    train_mod.main(common + ["OUTPUT_DIR=%s" % (tmp_path / "b"), "TRAIN.END_EPOCH=1"])
+    first = torch.load(tmp_path / "b" / "checkpoint.pth", map_location="cpu", weights_only=True)
+    assert first["epoch"] == 0 and first["optimizer"]["flat_momentum"] is not None
+    torch.manual_seed(123)  # a resumed run must not depend on the initialisation it overwrites
+    train_mod.main(common + ["OUTPUT_DIR=%s" % (tmp_path / "b"), "TRAIN.END_EPOCH=2",
+                             "TRAIN.RESUME=%s" % (tmp_path / "b" / "checkpoint.pth")])
+    resumed = torch.load(tmp_path / "b" / "checkpoint.pth", map_location="cpu", weights_only=True)
+    assert resumed["epoch"] == 1 and resumed["lr_scheduler"]["last_epoch"] == full["lr_scheduler"]["last_epoch"] == 2
+    w = lambda ck: torch.cat([v.flatten().float() for k, v in sorted(ck["state_dict"].items()) if v.dtype.is_floating_point])
+    assert rel_l2(w(resumed), w(full)) <= 2e-3
+    assert rel_l2(resumed["optimizer"]["flat_momentum"], full["optimizer"]["flat_momentum"]) <= 5e-2
+    assert rel_l2(w(first), w(full)) > 1e-2, "the second epoch was expected to move the weights"
+    for h in list(logging.getLogger().handlers):
+        logging.getLogger().removeHandler(h)

@@ -52,3 +52,19 @@ __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
 
 // thread-local error text for the C ABI
 void vc_set_error(const char* fmt, ...);
+
+#if defined(__cplusplus)
+#include <mutex>
+// One-time set-up per device (kernel attributes such as the 160 KiB dynamic-LDS limit), safe when several host threads
+// launch on distinct streams at once: a plain `static bool done[dev]` is a data race there.
+struct VcPerDeviceOnce {
+    std::once_flag flag[64];
+    template <typename F>
+    void run(F&& fn) {
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64) std::call_once(flag[dev], fn);
+        else fn();
+    }
+};
+#endif

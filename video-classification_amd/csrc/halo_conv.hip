@@ -596,13 +596,8 @@ static int halo_lds(int NW, int CK, int npieces, int NB = 4) {
 template <int NW, int CK, bool PAD, int NB = 4>
 int launch_halo(const VcHaloParams& p, hipStream_t stream) {
     const int lds = halo_lds(NW, CK, p.npieces, NB);
-    static bool attr_set[64] = {false};  // per device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)halo_conv_kernel<NW, CK, PAD, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[dev] = true;
-    }
+    static VcPerDeviceOnce once;  // thread-safe, once per device
+    once.run([&]() { (void)hipFuncSetAttribute((const void*)halo_conv_kernel<NW, CK, PAD, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     dim3 grid(p.ntg * p.nseg, p.Cn / 64, p.splits > 1 ? p.splits : 1);
     (void)hipGetLastError();
     hipLaunchKernelGGL((halo_conv_kernel<NW, CK, PAD, NB>), grid, dim3(NW * 64), lds, stream, p);

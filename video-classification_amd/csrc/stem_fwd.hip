@@ -272,13 +272,8 @@ int vc_stem_fwd_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcSte
 }
 
 int vc_launch_stem_fwd(VcStemFwdParams& p, hipStream_t stream) {
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)stem_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[dev] = true;
-    }
+    static VcPerDeviceOnce once;  // thread-safe, once per device
+    once.run([&]() { (void)hipFuncSetAttribute((const void*)stem_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     (void)hipGetLastError();
     hipLaunchKernelGGL(stem_fwd_kernel, dim3(p.grid), dim3(NWAVE * 64), p.lds_bytes, stream, p);
     const hipError_t e = hipGetLastError();

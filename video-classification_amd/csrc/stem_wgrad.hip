@@ -212,13 +212,8 @@ int vc_stem_wgrad_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcS
 size_t vc_stem_wgrad_slab_bytes(const VcStemWgradParams& p) { return (size_t)p.grid * 64 * 1344 * sizeof(float); }
 
 int vc_launch_stem_wgrad(VcStemWgradParams& p, float* dws, hipStream_t stream) {
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)stem_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[dev] = true;
-    }
+    static VcPerDeviceOnce once;  // thread-safe, once per device
+    once.run([&]() { (void)hipFuncSetAttribute((const void*)stem_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     (void)hipGetLastError();
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(p.grid), dim3(NWAVE * 64), p.lds_bytes, stream, p);
     const hipError_t e = hipGetLastError();

@@ -278,13 +278,8 @@ int vc_launch_wgrad9(VcWgrad9Params& p, hipStream_t stream) {
     }
     const int HW = p.H * p.W;
     p.dHW = vc_make_fastdiv(HW), p.dT = vc_make_fastdiv(p.T), p.dW = vc_make_fastdiv(p.W);
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        (void)hipFuncSetAttribute((const void*)wgrad9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[dev] = true;
-    }
+    static VcPerDeviceOnce once;  // thread-safe, once per device
+    once.run([&]() { (void)hipFuncSetAttribute((const void*)wgrad9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (p.ndt < 1 || p.ndt > 3) p.dt0 = 0, p.ndt = 3;
     dim3 grid(p.ndt * (p.Cs / 64), p.Co / 64, p.splits);
     (void)hipGetLastError();

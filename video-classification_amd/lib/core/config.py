@@ -68,6 +68,7 @@ config.TRAIN.BATCH_SIZE = 32
 config.TRAIN.SHUFFLE = True
 config.TRAIN.PRINT_EVERY = 100
 config.TRAIN.BUCKET_MB = 32
+config.TRAIN.RESUME = ''  # checkpoint.pth written by train.py every epoch: model + optimizer + scheduler + epoch
 
 # testing
 config.TEST = AttrDict()

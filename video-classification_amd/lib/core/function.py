@@ -15,6 +15,7 @@ import logging
 import time
 
 import torch
+import torch.utils.data.distributed
 
 from utils.utils import AverageMeter, ChooseInput, rollout
 
@@ -89,13 +90,30 @@ def train(config, train_loader, model, criterion, optimizer, epoch):
                         vedio.shape[0] * config.TRAIN.TRAIN_STEP / max(batch_time.val, 1e-9))
 
 
+def _real_samples(loader):
+    """samples this rank really owns: DistributedSampler pads the index list with repeats so that every rank gets the
+    same count; the repeats come last in a rank's sequence and must not be counted twice in the accuracy."""
+    smp = getattr(loader, "sampler", None)
+    if isinstance(smp, torch.utils.data.distributed.DistributedSampler) and not smp.drop_last:
+        n = len(smp.dataset)
+        return (n - smp.rank + smp.num_replicas - 1) // smp.num_replicas
+    return None
+
+
 def validate(config, val_loader, model, criterion, epoch):
-    """returns top-1 accuracy in [0, 1] over the loader (all ranks, if distributed)."""
+    """returns top-1 accuracy in [0, 1] over the loader (all ranks, if distributed); top-5 and the loss are logged and
+    left in ``validate.last`` (dict: top1, top5, loss, count).  Reference loop: function.py:117-149 -- TEST_STEP inner
+    steps per batch whose scores a Score_Updater accumulates (the reference reads config.TRAIN.TEST_STEP at :129,
+    which does not exist; config.py:65 defines TEST.TEST_STEP).  Here an inner step is one temporal clip: raw uint8
+    videos are cut into TEST.TEST_STEP uniformly spaced clips by ChooseInput and their logits averaged; a batch that
+    already holds float clips (nothing to choose from) is scored once, one that holds N x V views once per view."""
     batch_time = AverageMeter()
     score_updater = Score_Updater()
     model.eval()
     dev = _device_of(model)
-    stat = torch.zeros(3, device=dev, dtype=torch.float64)  # correct, count, loss sum
+    stat = torch.zeros(4, device=dev, dtype=torch.float64)  # top-1 correct, count, loss sum, top-5 correct
+    limit = _real_samples(val_loader)
+    seen = 0
     with torch.no_grad():
         end = time.time()
         for i, (vedio, target) in enumerate(val_loader):
@@ -109,20 +127,37 @@ def validate(config, val_loader, model, criterion, epoch):
                 parts = [model(flat[s:s + chunk])[1] for s in range(0, n * v, chunk)]
                 score_updater.update(torch.cat(parts).view(n, v, -1).mean(1))
             else:
-                _, score, _ = model(ChooseInput(vedio, Act_Init()))
-                score_updater.update(score)
+                nsteps = max(1, int(config.TEST.TEST_STEP)) if vedio.dtype == torch.uint8 else 1
+                action = Act_Init()
+                for step in range(nsteps):
+                    action, score, _ = model(ChooseInput(vedio, action, step, nsteps))
+                    score_updater.update(score)
             score = score_updater.mean()
+            if limit is not None:  # drop the sampler's padding repeats (they are the tail of this rank's sequence)
+                keep = max(0, min(target.numel(), limit - seen))
+                seen += target.numel()
+                if keep == 0:
+                    continue
+                score, target = score[:keep], target[:keep]
             loss = criterion(score, target, None, None)
-            stat[0] += (score.argmax(1) == target).sum()
+            k = min(5, score.shape[1])
+            top = score.topk(k, dim=1).indices
+            stat[0] += (top[:, 0] == target).sum()
             stat[1] += target.numel()
             stat[2] += loss.double() * target.numel()
+            stat[3] += (top == target[:, None]).any(1).sum()
             batch_time.update(time.time() - end)
             end = time.time()
             if i % config.TEST.PRINT_EVERY == 0:
                 logger.info('Test [%d][%d/%d] time %.3f (%.3f)', epoch, i, len(val_loader), batch_time.val,
                             batch_time.avg)
     stat = _distributed_sum(stat).cpu()
-    acc = float(stat[0] / stat[1].clamp_min(1))
-    logger.info('Test epoch %d: top-1 %.4f loss %.4f (%d videos)', epoch, acc, float(stat[2] / stat[1].clamp_min(1)),
-                int(stat[1]))
+    n = stat[1].clamp_min(1)
+    acc = float(stat[0] / n)
+    validate.last = {"top1": acc, "top5": float(stat[3] / n), "loss": float(stat[2] / n), "count": int(stat[1])}
+    logger.info('Test epoch %d: top-1 %.4f top-5 %.4f loss %.4f (%d videos)', epoch, acc, validate.last["top5"],
+                validate.last["loss"], int(stat[1]))
     return acc
+
+
+validate.last = None

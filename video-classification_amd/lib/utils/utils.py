@@ -44,12 +44,14 @@ class AverageMeter(object):
         self.avg = self.sum / self.count if self.count else 0
 
 
-def ChooseInput(vedio, action):
+def ChooseInput(vedio, action, step=0, nsteps=1):
     """reference utils.py:57-64 is an empty stub (frame/modality picking of the unfinished RL
     design).  Here the whole clip is the model input whatever the action.
     Raw decoded frames (uint8 N x Ts x Hs x Ws x 3 on the GPU) are turned into the model's input here, in one
     GPU pass (vc_clip_pack_u8): CLIP_LEN frames every FRAME_STEP, a CROP_SIZE crop, normalised with MODEL.MEAN/STD;
-    random position and horizontal flip while gradients are on (training), centred otherwise."""
+    random position and horizontal flip while gradients are on (training), centred otherwise.  With nsteps > 1
+    (validate's TEST.TEST_STEP inner steps) and gradients off, inner step k takes the k-th of nsteps uniformly spaced
+    temporal clips of the video (centre crop): the multi-clip test protocol."""
     if vedio.dtype != torch.uint8:
         return vedio
     from core.config import config as cfg
@@ -57,10 +59,10 @@ def ChooseInput(vedio, action):
     if vedio.dim() != 5 or vedio.shape[-1] != 3:
         raise ValueError("raw frames must be uint8 N x Ts x Hs x Ws x 3, got %s" % (tuple(vedio.shape),))
     N, Ts, Hs, Ws, _ = vedio.shape
-    T, S, step = cfg.MODEL.CLIP_LEN, cfg.MODEL.CROP_SIZE, cfg.MODEL.FRAME_STEP
-    span = (T - 1) * step + 1
+    T, S, fstep = cfg.MODEL.CLIP_LEN, cfg.MODEL.CROP_SIZE, cfg.MODEL.FRAME_STEP
+    span = (T - 1) * fstep + 1
     if Ts < span or Hs < S or Ws < S:
-        raise ValueError("frames %dx%dx%d are smaller than the clip %dx%dx%d (step %d)" % (Ts, Hs, Ws, T, S, S, step))
+        raise ValueError("frames %dx%dx%d are smaller than the clip %dx%dx%d (step %d)" % (Ts, Hs, Ws, T, S, S, fstep))
     crops = torch.empty(N, 4, dtype=torch.int32)
     if torch.is_grad_enabled():
         crops[:, 0] = torch.randint(0, Ts - span + 1, (N,))
@@ -68,8 +70,9 @@ def ChooseInput(vedio, action):
         crops[:, 2] = torch.randint(0, Ws - S + 1, (N,))
         crops[:, 3] = torch.randint(0, 2, (N,))
     else:
-        crops[:, 0], crops[:, 1], crops[:, 2], crops[:, 3] = (Ts - span) // 2, (Hs - S) // 2, (Ws - S) // 2, 0
-    return ops.clip_pack_u8(vedio.contiguous(), crops, T, S, S, step, cfg.MODEL.MEAN, cfg.MODEL.STD)
+        t0 = (Ts - span) // 2 if nsteps <= 1 else int(round(step * (Ts - span) / float(nsteps - 1)))
+        crops[:, 0], crops[:, 1], crops[:, 2], crops[:, 3] = t0, (Hs - S) // 2, (Ws - S) // 2, 0
+    return ops.clip_pack_u8(vedio.contiguous(), crops, T, S, S, fstep, cfg.MODEL.MEAN, cfg.MODEL.STD)
 
 
 def rollout(vedio, model, action, value):
@@ -87,8 +90,15 @@ def create_logger(cfg, phase='train'):
     logger = logging.getLogger()
     logger.setLevel(logging.INFO)
     fmt = logging.Formatter('%(asctime)-15s: %(message)s')
+    # idempotent, like the reference's logging.basicConfig: a second call in one process (train.py then valid.py, the
+    # tests) replaces the handlers this function added instead of stacking new ones (every line would print twice)
+    for h in [h for h in logger.handlers if getattr(h, "_vc_handler", False)]:
+        logger.removeHandler(h)
+        h.close()
     fh = logging.FileHandler(path)
     fh.setFormatter(fmt)
-    logger.addHandler(fh)
-    logger.addHandler(logging.StreamHandler())
+    sh = logging.StreamHandler()
+    for h in (fh, sh):
+        h._vc_handler = True
+        logger.addHandler(h)
     return logger

@@ -49,6 +49,8 @@ def apply_overrides(cfg, argv):
             val = val.lower() in ("1", "true", "yes")
         elif isinstance(old, list):
             val = [type(old[0])(v) if old else (int(v) if v.lstrip('-').isdigit() else float(v)) for v in val.split(",") if v]
+        elif isinstance(old, int):  # an integer default (LR_DECAY_RATE = 1) may be overridden by a fraction
+            val = int(val) if val.lstrip('-').isdigit() else float(val)
         elif old is not None:
             val = type(old)(val)
         node[parts[-1]] = val
@@ -92,7 +94,20 @@ def main(argv=None):
     train_loader = make_loader(cfg, True, world, rank, n_train)
     valid_loader = make_loader(cfg, False, world, rank, n_val)
     best_perf = -1.0
-    for epoch in range(cfg.TRAIN.BEGIN_EPOCH, cfg.TRAIN.END_EPOCH):
+    begin_epoch = cfg.TRAIN.BEGIN_EPOCH
+    ckpt_path = os.path.join(cfg.OUTPUT_DIR, 'checkpoint.pth')
+    resume = cfg.TRAIN.RESUME or (ckpt_path if cfg.TRAIN.BEGIN_EPOCH > 0 and os.path.isfile(ckpt_path) else '')
+    if resume:
+        # reference config.py:53 has BEGIN_EPOCH but nothing restores the optimizer; here a run continues exactly where it
+        # stopped: weights, BatchNorm buffers, momentum, learning-rate schedule, best accuracy, next epoch
+        ck = torch.load(resume, map_location='cpu', weights_only=True)
+        model.load_state_dict({(k[7:] if k.startswith('module.') else k): v for k, v in ck['state_dict'].items()})
+        optimizer.load_state_dict(ck['optimizer'])
+        lr_scheduler.load_state_dict(ck['lr_scheduler'])
+        best_perf = float(ck.get('best_perf', -1.0))
+        begin_epoch = max(begin_epoch, int(ck['epoch']) + 1)
+        logger.info('=> resumed from %s: next epoch %d, best top-1 %.4f', resume, begin_epoch, best_perf)
+    for epoch in range(begin_epoch, cfg.TRAIN.END_EPOCH):
         if world > 1:
             train_loader.sampler.set_epoch(epoch)
         train(cfg, train_loader, net, criterion, optimizer, epoch)
@@ -104,6 +119,9 @@ def main(argv=None):
                 path = os.path.join(cfg.OUTPUT_DIR, 'model_best.pth')
                 torch.save({'state_dict': model.state_dict(), 'epoch': epoch, 'perf': best_perf}, path)
                 logger.info('=> saved best model (top-1 %.4f) to %s', best_perf, path)
+        if rank == 0:
+            torch.save({'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict(),
+                        'lr_scheduler': lr_scheduler.state_dict(), 'epoch': epoch, 'best_perf': best_perf}, ckpt_path)
     if world > 1:
         dist.destroy_process_group()
     return best_perf

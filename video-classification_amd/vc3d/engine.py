@@ -304,6 +304,26 @@ class R3DEngine:
         return d, y, params
 
     def forward(self, x, training, save):
+        try:
+            return self._forward(x, training, save)
+        except Vc3dError:
+            self._reset_tickets()
+            raise
+
+    def backward(self, saved, dfeat):
+        try:
+            return self._backward(saved, dfeat)
+        except Vc3dError:
+            self._reset_tickets()
+            raise
+
+    def _reset_tickets(self):
+        """a launch that failed midway may leave ticket words of the fused BatchNorm finalize non-zero (they are only
+        reset by the workgroup that draws the last ticket): zero them so the next step starts clean."""
+        if self._tickets is not None:
+            self._tickets.zero_()
+
+    def _forward(self, x, training, save):
         """x: [N][3][T][H][W] fp32/bf16 on the GPU.  Returns (features fp32 [N][F], saved state)."""
         packed = isinstance(x, ops.PackedClips)  # from ops.clip_pack_u8: already the stem's packed source
         if x.dim() != 5 or x.shape[1] != 3:
@@ -389,7 +409,7 @@ class R3DEngine:
         return feat, saved
 
     # ------------------------------------------------------------------ backward
-    def backward(self, saved, dfeat):
+    def _backward(self, saved, dfeat):
         """dfeat: fp32 [N][F].  Writes every backbone parameter gradient (accumulating)."""
         dev = dfeat.device
         self._main = torch.cuda.current_stream()

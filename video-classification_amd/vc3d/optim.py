@@ -50,9 +50,12 @@ class FlatSGD(torch.optim.Optimizer):
         eng = self._engine_ready()
         for p in eng.plist:  # gradients that did not come from the engine's backward: move them in
             v = eng.grad_views[id(p)]
-            if p.grad is None:
-                v.zero_()
-            elif p.grad.data_ptr() != v.data_ptr():
+            if p.grad is None or not p.requires_grad:
+                # torch.optim.SGD skips such a parameter altogether (no weight decay, no momentum update); the one-launch
+                # step over the flat buffer cannot, so this is refused rather than silently trained
+                raise Vc3dError("FlatSGD: every parameter needs a gradient (frozen or unused parameters are not "
+                                "supported by the fused step; use torch.optim.SGD for them)")
+            if p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v
         g = self.param_groups[0]
@@ -70,4 +73,5 @@ class FlatSGD(torch.optim.Optimizer):
         sd = dict(sd)
         mom = sd.pop("flat_momentum", None)
         super().load_state_dict(sd)
-        self.mom = None if mom is None else mom.clone()
+        dev = next(self.core.parameters()).device
+        self.mom = None if mom is None else mom.detach().to(device=dev, dtype=torch.float32).clone()
