@@ -556,3 +556,58 @@ def test_concurrent_host_threads_on_distinct_streams():
         ref = ops.conv3d_fwd(d, x, w)
         torch.cuda.synchronize()
         assert torch.equal(ref.view(torch.int16), y.view(torch.int16))
+
+
+def test_kernels_beyond_two_giga_elements():
+    """BASELINE config 4 (64 x 224 x 224 clips) at batch 64 puts 3.3 G elements into one tensor.  The bandwidth kernels
+    take 64-bit element counts; the conv entry points run sub-batches (capi.hip conv_max_batch).  Checked here on a
+    2.3 G-element tensor (36 M rows x 64 channels, 4.6 GB): each op on the whole tensor equals the same op on its last
+    slice alone (the part whose offsets do not fit 32 bits) -- exact equality for the element-wise ops, 1e-5 on sums."""
+    from vc3d import ops
+    C = 64
+    N, T, H, W = 46, 16, 224, 224  # N*T*H*W*C = 2.36e9 > 2^31; one sample = 51 M elements
+    g = torch.Generator(device="cuda").manual_seed(3)
+    y = torch.empty(N, T, H, W, C, dtype=torch.bfloat16, device="cuda")
+    for n in range(N):
+        y[n] = torch.randn(T, H, W, C, device="cuda", generator=g).to(torch.bfloat16)
+    assert y.numel() > 2 ** 31
+    prm = torch.stack([0.1 * torch.randn(C, device="cuda", generator=g), 1 + 0.1 * torch.rand(C, device="cuda", generator=g),
+                       1 + 0.1 * torch.rand(C, device="cuda", generator=g), 0.1 * torch.randn(C, device="cuda", generator=g)])
+    tail = slice(N - 4, N)
+    # BatchNorm apply (+ReLU)
+    z = ops.bn_apply(y, prm, C, relu=True)
+    z_t = ops.bn_apply(y[tail].contiguous(), prm, C, relu=True)
+    assert torch.equal(z[tail], z_t)
+    # statistics: whole = sum of the per-sample-group sums
+    st = ops.bn_stats(y, C).sum(0)
+    st_parts = sum(ops.bn_stats(y[a:a + 8].contiguous(), C).sum(0) for a in range(0, N, 8))
+    assert torch.allclose(st, st_parts, rtol=1e-5, atol=1e-2)
+    # BatchNorm backward apply (mask recomputed from y) on the tail
+    dz = z  # any tensor of the same shape serves as the incoming gradient
+    coef = torch.stack([0.01 * torch.randn(C, device="cuda", generator=g), 0.01 * torch.randn(C, device="cuda", generator=g)])
+    from vc3d import capi
+    dy = torch.empty_like(y)
+    capi.check(capi.lib.vc_bn_bwd_apply(y.data_ptr(), dz.data_ptr(), None, prm.data_ptr(), coef.data_ptr(), dy.data_ptr(), None,
+                                        y.numel(), C, 2, capi.cur_stream()))
+    yt, dzt = y[tail].contiguous(), dz[tail].contiguous()
+    dy_t = torch.empty_like(yt)
+    capi.check(capi.lib.vc_bn_bwd_apply(yt.data_ptr(), dzt.data_ptr(), None, prm.data_ptr(), coef.data_ptr(), dy_t.data_ptr(), None,
+                                        yt.numel(), C, 2, capi.cur_stream()))
+    assert torch.equal(dy[tail], dy_t)
+    del dy, dy_t, dz, z_t
+    # max pool with the fused BatchNorm + ReLU, and the BatchNorm backward through the pool
+    pd = ops.pool_desc(N, C, T, H, W)
+    out, idx = ops.maxpool3d_fwd(pd, y, prm)
+    pd_t = ops.pool_desc(4, C, T, H, W)
+    out_t, idx_t = ops.maxpool3d_fwd(pd_t, yt, prm)
+    assert torch.equal(out[tail], out_t) and torch.equal(idx[tail], idx_t)
+    dgam, dbet = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dpool = out  # gradient stand-in
+    dy0 = ops.bn_bwd_pooled(pd, y, dpool, idx, prm, C, dgam, dbet, pooled=out)
+    assert bool(torch.isfinite(dy0[tail].float()).all()) and float(dy0[tail].float().abs().sum()) > 0
+    # conv through the C ABI: 1x1x1, whole batch (sub-batches inside) == last samples alone
+    d = ops.conv_desc(N, C, T, H, W, 64, 1, 1, 0)
+    wf = (0.1 * torch.randn(64, C, device="cuda", generator=g)).to(torch.bfloat16)
+    yo = ops.conv3d_fwd(d, y, wf)
+    yo_t = ops.conv3d_fwd(ops.conv_desc(4, C, T, H, W, 64, 1, 1, 0), yt, wf)
+    assert torch.equal(yo[tail], yo_t)

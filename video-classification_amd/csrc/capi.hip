@@ -51,11 +51,25 @@ static int conv_check(const vc_conv3d_desc* d, int& To, int& Ho, int& Wo) {
     if (rc) return rc;
     VC_REQUIRE(d->Ci % 64 == 0 && d->Co % 64 == 0, "conv3d: Ci=%d and Co=%d must be multiples of 64", d->Ci, d->Co);
     VC_REQUIRE(d->kt * d->kh * d->kw <= 32, "conv3d: at most 32 taps (got %d)", d->kt * d->kh * d->kw);
-    const long long in_e = (long long)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
-    const long long out_e = (long long)d->N * To * Ho * Wo * d->Co;
-    VC_REQUIRE(in_e < (1ll << 31) && out_e < (1ll << 31),
-               "conv3d: tensor exceeds 2^31 elements; split the batch (in=%lld out=%lld)", in_e, out_e);
+    const long long in_s = (long long)d->Ti * d->Hi * d->Wi * d->Ci;
+    const long long out_s = (long long)To * Ho * Wo * d->Co;
+    VC_REQUIRE(in_s < (1ll << 31) && out_s < (1ll << 31),
+               "conv3d: one sample exceeds 2^31 elements (in=%lld out=%lld)", in_s, out_s);
     return 0;
+}
+
+// The kernels index a tensor with 32-bit element offsets.  A batch whose input or output exceeds 2^31 elements (64 clips
+// of 64 x 224 x 224 at the stem's output) is run as consecutive sub-batches inside the entry point: samples do not
+// interact in a conv, BatchNorm sums accumulate across the launches (atomics into the same buffer), weight gradients
+// accumulate by construction, and the fused finalize (one launch's ticket) becomes the separate finalize launch after
+// the last sub-batch.  Returns the largest sub-batch (== N when no split is needed).
+static int conv_max_batch(const vc_conv3d_desc* d, int To, int Ho, int Wo) {
+    const long long in_s = (long long)d->Ti * d->Hi * d->Wi * d->Ci;
+    const long long out_s = (long long)To * Ho * Wo * d->Co;
+    const long long big = in_s > out_s ? in_s : out_s;
+    long long nmax = ((1ll << 31) - 1) / big;
+    if (nmax < 1) nmax = 1;
+    return nmax < d->N ? (int)nmax : d->N;
 }
 
 static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const void* w, void* out, float* stats,
@@ -188,7 +202,21 @@ static int dgrad_splits(const vc_conv3d_desc* d) {
     return vc_igemm_splits(d->N * Ta * Ha * Wa, d->Ci, taps * (d->Co / 64));
 }
 
+static size_t workspace_bytes_one(const vc_conv3d_desc* d, int32_t op);
+
 size_t vc_conv3d_workspace_bytes(const vc_conv3d_desc* d, int32_t op) {
+    int To, Ho, Wo;
+    if (conv_check(d, To, Ho, Wo)) return 0;
+    const int nb = conv_max_batch(d, To, Ho, Wo);
+    if (nb == d->N) return workspace_bytes_one(d, op);
+    vc_conv3d_desc a = *d, b = *d;  // full sub-batches and the remainder
+    a.N = nb;
+    b.N = d->N % nb;
+    const size_t wa = workspace_bytes_one(&a, op), wb = b.N > 0 ? workspace_bytes_one(&b, op) : 0;
+    return wa > wb ? wa : wb;
+}
+
+static size_t workspace_bytes_one(const vc_conv3d_desc* d, int32_t op) {
     int To, Ho, Wo;
     if (conv_check(d, To, Ho, Wo)) return 0;
     if ((op == 0 || op == 1) && halo_ok(d)) {
@@ -226,6 +254,20 @@ static int conv3d_fwd_impl(const vc_conv3d_desc* d, const void* x, const void* w
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(x && w && y, "conv3d_fwd: null pointer");
+    const int nb = conv_max_batch(d, To, Ho, Wo);
+    if (nb < d->N) {  // sub-batches (see conv_max_batch)
+        const size_t in_s = (size_t)d->Ti * d->Hi * d->Wi * d->Ci, out_s = (size_t)To * Ho * Wo * d->Co;
+        for (int n0 = 0; n0 < d->N; n0 += nb) {
+            vc_conv3d_desc sub = *d;
+            sub.N = d->N - n0 < nb ? d->N - n0 : nb;
+            rc = conv3d_fwd_impl(&sub, (const bf16*)x + n0 * in_s, w, (bf16*)y + n0 * out_s, bn_stats, nullptr, ep_params, ep_relu,
+                                 ep_res ? (const bf16*)ep_res + n0 * out_s : nullptr, workspace, ws_bytes, stream);
+            if (rc) return rc;
+        }
+        if (fin == nullptr || bn_stats == nullptr) return 0;
+        return vc_ew_bn_finalize(bn_stats, d->Co, fin->count, fin->gamma, fin->beta, fin->running_mean, fin->running_var,
+                                 fin->momentum, fin->eps, fin->params, S(stream));
+    }
     if (halo_ok(d)) return halo_run(d, false, x, w, y, bn_stats, fin, ep_params, ep_relu, ep_res, 0, workspace, ws_bytes, stream);
     VcIgemmParams p;
     memset(&p, 0, sizeof(p));
@@ -408,6 +450,18 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(dy && w_dgrad && dx, "conv3d_dgrad: null pointer");
+    const int nb = conv_max_batch(d, To, Ho, Wo);
+    if (nb < d->N) {  // sub-batches (see conv_max_batch)
+        const size_t in_s = (size_t)d->Ti * d->Hi * d->Wi * d->Ci, out_s = (size_t)To * Ho * Wo * d->Co;
+        for (int n0 = 0; n0 < d->N; n0 += nb) {
+            vc_conv3d_desc sub = *d;
+            sub.N = d->N - n0 < nb ? d->N - n0 : nb;
+            rc = vc_conv3d_dgrad(&sub, (const bf16*)dy + n0 * out_s, w_dgrad, (bf16*)dx + n0 * in_s, accumulate, workspace,
+                                 ws_bytes, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     if (halo_ok(d)) return halo_run(d, true, dy, w_dgrad, dx, nullptr, nullptr, nullptr, 0, nullptr, accumulate, workspace, ws_bytes, stream);
     const int ntaps_all = d->kt * d->kh * d->kw;
     const size_t dx_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
@@ -527,6 +581,17 @@ int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, floa
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
     VC_REQUIRE(x && dy && dw, "conv3d_wgrad: null pointer");
+    const int nb = conv_max_batch(d, To, Ho, Wo);
+    if (nb < d->N) {  // sub-batches (see conv_max_batch): dw accumulates
+        const size_t in_s = (size_t)d->Ti * d->Hi * d->Wi * d->Ci, out_s = (size_t)To * Ho * Wo * d->Co;
+        for (int n0 = 0; n0 < d->N; n0 += nb) {
+            vc_conv3d_desc sub = *d;
+            sub.N = d->N - n0 < nb ? d->N - n0 : nb;
+            rc = vc_conv3d_wgrad(&sub, (const bf16*)x + n0 * in_s, (const bf16*)dy + n0 * out_s, dw, workspace, ws_bytes, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     if (wgrad9_ok(d)) {
         int rps9 = 0;
         const int s9 = vc_wgrad9_plan((long)d->N * d->Ti * d->Hi * d->Wi, d->Wi, d->Ci, d->Co, d->Ti > 1 ? 3 : 1, &rps9);
@@ -632,10 +697,19 @@ static int stem_check(int N, int T, int H, int W, int Co) {
     VC_REQUIRE(N > 0 && T > 0 && H > 0 && W > 0, "stem: bad dims");
     VC_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H=%d and W=%d must be even", H, W);
     VC_REQUIRE(Co % 64 == 0 && Co > 0, "stem: Co=%d must be a multiple of 64", Co);
-    const long long in_e = (long long)N * (T + 6) * (H / 2 + 3) * ((W / 2 + 4) & ~1) * 12;
-    const long long out_e = (long long)N * T * (H / 2) * (W / 2) * Co;
-    VC_REQUIRE(in_e < (1ll << 31) && out_e < (1ll << 31), "stem: tensor exceeds 2^31 elements; split the batch");
+    const long long in_s = (long long)(T + 6) * (H / 2 + 3) * ((W / 2 + 4) & ~1) * 12;
+    const long long out_s = (long long)T * (H / 2) * (W / 2) * Co;
+    VC_REQUIRE(in_s < (1ll << 31) && out_s < (1ll << 31), "stem: one clip exceeds 2^31 elements");
     return 0;
+}
+// largest sub-batch whose packed source and output stay below 2^31 elements (the stem kernels index with 32 bits)
+static int stem_max_batch(int N, int T, int H, int W, int Co) {
+    const long long in_s = (long long)(T + 6) * (H / 2 + 3) * ((W / 2 + 4) & ~1) * 12;
+    const long long out_s = (long long)T * (H / 2) * (W / 2) * Co;
+    const long long big = in_s > out_s ? in_s : out_s;
+    long long nmax = ((1ll << 31) - 1) / big;
+    if (nmax < 1) nmax = 1;
+    return nmax < N ? (int)nmax : N;
 }
 
 size_t vc_stem_packed_input_elems(int32_t N, int32_t T, int32_t H, int32_t W) {
@@ -691,6 +765,18 @@ static int stem_fwd_impl(const void* xs, const void* ws, void* y, float* bn_stat
     int rc = stem_check(N, T, H, W, Co);
     if (rc) return rc;
     VC_REQUIRE(xs && ws && y, "stem_fwd: null pointer");
+    const int nb = stem_max_batch(N, T, H, W, Co);
+    if (nb < N) {  // sub-batches: BatchNorm sums accumulate across the launches, finalize after the last one
+        const size_t in_s = vc_stem_packed_input_elems(1, T, H, W), out_s = (size_t)T * (H / 2) * (W / 2) * Co;
+        for (int n0 = 0; n0 < N; n0 += nb) {
+            rc = stem_fwd_impl((const bf16*)xs + n0 * in_s, ws, (bf16*)y + n0 * out_s, bn_stats, nullptr, N - n0 < nb ? N - n0 : nb, T,
+                               H, W, Co, stream);
+            if (rc) return rc;
+        }
+        if (fin == nullptr || bn_stats == nullptr) return 0;
+        return vc_ew_bn_finalize(bn_stats, Co, fin->count, fin->gamma, fin->beta, fin->running_mean, fin->running_var,
+                                 fin->momentum, fin->eps, fin->params, S(stream));
+    }
     int M, Ho, Wo, Tp, Hp, Wp;
     stem_geometry(N, T, H, W, M, Ho, Wo, Tp, Hp, Wp);
     VcStemFwdParams sp;
@@ -734,6 +820,12 @@ int vc_stem_fwd_bn(const void* xs, const void* ws, void* y, float* bn_stats, con
 
 size_t vc_stem_wgrad_workspace_bytes(int32_t N, int32_t T, int32_t H, int32_t W, int32_t Co) {
     if (stem_check(N, T, H, W, Co)) return 0;
+    const int nb = stem_max_batch(N, T, H, W, Co);
+    if (nb < N) {
+        const size_t wa = vc_stem_wgrad_workspace_bytes(nb, T, H, W, Co);
+        const size_t wb = N % nb ? vc_stem_wgrad_workspace_bytes(N % nb, T, H, W, Co) : 0;
+        return wa > wb ? wa : wb;
+    }
     int M, Ho, Wo, Tp, Hp, Wp;
     stem_geometry(N, T, H, W, M, Ho, Wo, Tp, Hp, Wp);
     VcStemWgradParams sp;
@@ -746,6 +838,16 @@ int vc_stem_wgrad(const void* xs, const void* dy, float* dws, int32_t N, int32_t
     int rc = stem_check(N, T, H, W, Co);
     if (rc) return rc;
     VC_REQUIRE(xs && dy && dws, "stem_wgrad: null pointer");
+    const int nb = stem_max_batch(N, T, H, W, Co);
+    if (nb < N) {  // sub-batches: dws accumulates
+        const size_t in_s = vc_stem_packed_input_elems(1, T, H, W), out_s = (size_t)T * (H / 2) * (W / 2) * Co;
+        for (int n0 = 0; n0 < N; n0 += nb) {
+            rc = vc_stem_wgrad((const bf16*)xs + n0 * in_s, (const bf16*)dy + n0 * out_s, dws, N - n0 < nb ? N - n0 : nb, T, H, W, Co,
+                               workspace, ws_bytes, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     int M, Ho, Wo, Tp, Hp, Wp;
     stem_geometry(N, T, H, W, M, Ho, Wo, Tp, Hp, Wp);
     // image-resident form (persistent workgroups, per-workgroup fp32 slabs in the workspace)
