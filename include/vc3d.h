@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define VC_STAT_REPLICAS 32
-#define VC_ABI_VERSION 1
+#define VC_ABI_VERSION 2
 
 typedef struct vc_conv3d_desc {
     int32_t N, Ci, Ti, Hi, Wi; /* input  [N][Ti][Hi][Wi][Ci] */
@@ -75,6 +75,13 @@ typedef struct vc_bn_fin {
     float* running_var;
     float* params;       /* out [4][C]: mean, invstd, scale, shift (as vc_bn_finalize) */
     float count, momentum, eps;
+    /* Shifted sums (numerics): with `shift` ([C], nullable) the launch accumulates sum (y - shift) and sum (y - shift)^2,
+     * and the finalize adds the shift back: var = E[(y-s)^2] - E[y-s]^2 does not cancel when |mean| >> sigma as long as
+     * s is within a few sigma of the mean.  `shift_next` ([C], nullable, may alias shift) receives this batch's mean:
+     * pass the same buffer step after step and the shift tracks the mean (first step: zeros, or vc_bn_stats' row-0
+     * shift for a robust first estimate). */
+    const float* shift;
+    float* shift_next;
 } vc_bn_fin;
 int vc_conv3d_fwd_bn(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats,
                      const vc_bn_fin* fin, void* workspace, size_t ws_bytes, void* stream);
@@ -155,10 +162,13 @@ int vc_stem_unpack_wgrad(const float* dws, float* dw_master /* [Co][7][7][7][3],
 /* ---- BatchNorm3d (+ReLU, +residual).  Replaces nn.BatchNorm2d / nn.ReLU / `out += residual`
  * at reference lib/models/backbone.py:39-42,50-51,54,59-60 (BasicBlock), :71-79,87-101
  * (Bottleneck), :114-115,146-147 (stem), :133 (downsample); BN_MOMENTUM :13. */
-int vc_bn_stats(const void* y, float* sums, int64_t rows, int32_t C, void* stream);
+/* shift_out (nullable, [C]): the sums are taken relative to row 0 of y (a value within a few sigma of the channel
+ * mean, known to every workgroup without a pass of its own) and that row is written to shift_out for vc_bn_finalize. */
+int vc_bn_stats(const void* y, float* sums, float* shift_out, int64_t rows, int32_t C, void* stream);
+/* shift (nullable): what the sums were taken relative to; shift_next (nullable, may alias): receives the mean */
 int vc_bn_finalize(const float* stats, int32_t C, float count, const float* gamma, const float* beta,
                    float* running_mean /* nullable */, float* running_var, float momentum, float eps,
-                   float* params, void* stream);
+                   float* params, const float* shift, float* shift_next, void* stream);
 int vc_bn_eval_params(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* params, void* stream);
 int vc_bn_apply(const void* y, const float* params, const void* residual /* nullable */, void* out,

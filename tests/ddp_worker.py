@@ -121,10 +121,12 @@ def main_shards():
         cfg, model, crit, opt = build()
         model.train()
         opt.zero_grad()
+        eng = model.backbone.engine
         for r in range(world):  # sequential micro-shards: per-shard BatchNorm statistics, gradients accumulate
             _, score, _ = model(x[r * per:(r + 1) * per])
             crit(score, y[r * per:(r + 1) * per], None, None).backward()
-        eng = model.backbone.engine
+            for cb in eng.all_convbn():  # a rank's first step takes its BatchNorm sums relative to a zero shift: the
+                cb.shift.zero_()         # emulation must too, or the sums differ in their last bits (and then see above)
         eng.flat_grad.div_(world)
         opt.step()
         torch.cuda.synchronize()

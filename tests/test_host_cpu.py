@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, s), "libvc3d.so does not export %s" % s
     assert set(capi.PROTOTYPES) == set(syms), "ctypes binding and header disagree: %s" % (
         set(capi.PROTOTYPES) ^ set(syms))
-    assert capi.lib.vc_abi_version() == 1
+    assert capi.lib.vc_abi_version() == 2
 
 
 def test_host_side_shape_logic():

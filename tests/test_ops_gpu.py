@@ -611,3 +611,55 @@ def test_kernels_beyond_two_giga_elements():
     yo = ops.conv3d_fwd(d, y, wf)
     yo_t = ops.conv3d_fwd(ops.conv_desc(4, C, T, H, W, 64, 1, 1, 0), yt, wf)
     assert torch.equal(yo[tail], yo_t)
+
+
+def test_batchnorm_variance_survives_a_large_mean():
+    """SURVEY section 7 flagged var = sum x^2 / n - mean^2 in fp32 as cancellation-prone.  The sums are shifted now
+    (bn_fin.h): stand-alone statistics relative to row 0 of the tensor, fused conv-epilogue statistics relative to a
+    caller-held shift that the finalize refreshes with the batch mean.  Stress: |mean| / sigma = 100.
+      (a) vc_bn_stats + vc_bn_finalize on 64 channels x 3.2 M values (the stem's size): variance within 1e-3 of the
+          fp64 variance of the same bf16 values, mean within 1e-6 relative; the unshifted form is shown beside it;
+      (b) the fused path (1x1x1 conv, statistics from the fp32 accumulators, finalize by the last workgroup): first
+          call with a zero shift (unshifted, may be off), second call with the shift the first one left: <= 1e-3."""
+    from vc3d import capi, ops
+    C, rows = 64, 3_211_264  # 64 x 16 x 56 x 56
+    g = torch.Generator(device="cuda").manual_seed(8)
+    sigma = 0.5 + torch.rand(C, device="cuda", generator=g)
+    y = torch.empty(rows, C, dtype=torch.bfloat16, device="cuda")
+    for a in range(0, rows, 401408):
+        y[a:a + 401408] = (100.0 * sigma + sigma * torch.randn(401408, C, device="cuda", generator=g)).to(torch.bfloat16)
+    yd = y.double()
+    mean64, var64 = yd.mean(0), yd.var(0, unbiased=False)
+    del yd
+    gamma, beta = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    res = {}
+    for tag, use_shift in (("shifted", True), ("unshifted", False)):
+        shift = torch.zeros(C, device="cuda") if use_shift else None
+        sums = ops.bn_stats(y, C, shift=shift)
+        prm = ops.bn_finalize(sums, rows, gamma, beta, None, None, 0.1, 0.0, shift=shift)
+        var = 1.0 / prm[1].double() ** 2
+        res[tag] = (float(((prm[0].double() - mean64).abs() / mean64.abs()).max()), float(((var - var64).abs() / var64).max()))
+    print("stand-alone statistics at |mean|/sigma = 100: (mean rel err, var rel err)", res)
+    assert res["shifted"][0] <= 1e-6 and res["shifted"][1] <= 1e-3
+    # (b) fused: y = conv1x1x1(x), x = 1 + 0.08 r, w = 1/64 (exact in bf16)  ->  mean 1, sigma 0.01
+    N, T, H, W = 16, 8, 28, 28
+    x = (1.0 + 0.08 * torch.randn(N, T, H, W, 64, device="cuda", generator=g)).to(torch.bfloat16)
+    wf = torch.full((64, 64), 1.0 / 64, dtype=torch.bfloat16, device="cuda")
+    yref = x.double().sum(-1, keepdim=True) / 64.0  # every output channel is the same exact mean of the 64 inputs
+    m64, v64 = float(yref.mean()), float(yref.var(unbiased=False))
+    assert abs(m64) / v64 ** 0.5 > 80
+    d = ops.conv_desc(N, 64, T, H, W, 64, 1, 1, 0)
+    shift = torch.zeros(64, device="cuda")
+    ticket = torch.zeros(capi.VC_TICKET_WORDS, dtype=torch.int32, device="cuda")
+    errs = []
+    for call in range(2):
+        stats = ops.new_stats(64, x.device)
+        fin, prm = ops.bn_fin(ticket, N * T * H * W, gamma, beta, None, None, 0.1, 0.0, shift=shift)
+        ops.conv3d_fwd(d, x, wf, stats=stats, fin=fin)
+        torch.cuda.synchronize()
+        var = 1.0 / prm[1].double() ** 2
+        errs.append((float((prm[0].double() - m64).abs().max() / abs(m64)), float(((var - v64).abs() / v64).max())))
+    print("fused conv statistics at |mean|/sigma = %.0f: call 1 (zero shift) %s, call 2 (shift = last mean) %s"
+          % (abs(m64) / v64 ** 0.5, errs[0], errs[1]))
+    assert float((shift.double() - m64).abs().max()) <= 1e-5 * abs(m64)
+    assert errs[1][0] <= 1e-6 and errs[1][1] <= 1e-3

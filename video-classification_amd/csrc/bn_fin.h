@@ -19,6 +19,12 @@ struct VcBnFin {  // forward: sums (sum y, sum y^2) -> params [4][C] = mean, inv
     float* running_var;
     float* params;
     float count, momentum, eps;
+    // Shifted sums: the producers accumulate sum (y - shift[c]) and sum (y - shift[c])^2, so that a channel whose mean is
+    // far from zero compared with its spread does not lose its variance to cancellation in fp32
+    // (var = E[(y-s)^2] - E[y-s]^2 is exact in the limit s = mean; s = 0 is the textbook one-pass form).  Any shift
+    // within a few sigma of the mean will do: the engine passes the batch mean of the previous step.
+    const float* shift;   // nullable: [C], the shift the sums were taken with (null = 0)
+    float* shift_out;     // nullable: [C], receives this batch's mean (may alias shift: the next step's shift)
 };
 struct VcBnBwdFin {  // backward: sums (sum g, sum g*xhat) -> coef [2][C]; dgamma += sum g*xhat; dbeta += sum g
     unsigned* ticket;
@@ -45,12 +51,15 @@ __device__ __forceinline__ void vc_stat_sum(const float* stats, int C, int c, fl
 template <bool AGENT>
 __device__ __forceinline__ void vc_bn_finalize_channel(const float* stats, int C, int c, float count, const float* gamma,
                                                        const float* beta, float* running_mean, float* running_var,
-                                                       float momentum, float eps, float* params) {
+                                                       float momentum, float eps, float* params,
+                                                       const float* shift = nullptr, float* shift_out = nullptr) {
     float s, q;
     vc_stat_sum<AGENT>(stats, C, c, s, q);
-    const float mean = s / count;
-    float var = q / count - mean * mean;
+    const float m1 = s / count;  // mean of (y - shift)
+    const float mean = (shift != nullptr ? shift[c] : 0.f) + m1;
+    float var = q / count - m1 * m1;
     var = var > 0.f ? var : 0.f;
+    if (shift_out != nullptr) shift_out[c] = mean;
     const float invstd = rsqrtf(var + eps);
     const float scale = gamma[c] * invstd;
     params[c] = mean;
@@ -124,7 +133,7 @@ __device__ __forceinline__ void vc_bn_fin_last(const VcBnFin& f, const float* st
     if (!vc_last_workgroup(f.ticket)) return;
     for (int c = threadIdx.x; c < C; c += blockDim.x)
         vc_bn_finalize_channel<true>(stats, C, c, f.count, f.gamma, f.beta, f.running_mean, f.running_var, f.momentum,
-                                     f.eps, f.params);
+                                     f.eps, f.params, f.shift, f.shift_out);
 }
 __device__ __forceinline__ void vc_bn_bwd_fin_last(const VcBnBwdFin& f, const float* sums, int C) {
     if (f.ticket == nullptr || sums == nullptr) return;

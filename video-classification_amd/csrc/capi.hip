@@ -266,7 +266,7 @@ static int conv3d_fwd_impl(const vc_conv3d_desc* d, const void* x, const void* w
         }
         if (fin == nullptr || bn_stats == nullptr) return 0;
         return vc_ew_bn_finalize(bn_stats, d->Co, fin->count, fin->gamma, fin->beta, fin->running_mean, fin->running_var,
-                                 fin->momentum, fin->eps, fin->params, S(stream));
+                                 fin->momentum, fin->eps, fin->params, fin->shift, fin->shift_out, S(stream));
     }
     if (halo_ok(d)) return halo_run(d, false, x, w, y, bn_stats, fin, ep_params, ep_relu, ep_res, 0, workspace, ws_bytes, stream);
     VcIgemmParams p;
@@ -309,7 +309,7 @@ static int conv3d_fwd_impl(const vc_conv3d_desc* d, const void* x, const void* w
         if (rc || ep_params == nullptr) return rc;
         return vc_ew_bn_apply(y, ep_params, ep_res, y, (long)out_e, d->Co, ep_relu, S(stream));  // in place
     }
-    if (fin != nullptr && bn_stats != nullptr) p.fin = *fin;
+    if (fin != nullptr && bn_stats != nullptr) p.fin = *fin, p.stat_shift = fin->shift;
     p.ep_params = ep_params, p.ep_relu = ep_relu, p.ep_res = (const bf16*)ep_res;
     return vc_launch_igemm(p, 0, S(stream));
 }
@@ -322,6 +322,7 @@ static int make_fin(const vc_bn_fin* f, const float* stats, VcBnFin& o) {
     o.ticket = f->ticket, o.gamma = f->gamma, o.beta = f->beta;
     o.running_mean = f->running_mean, o.running_var = f->running_var, o.params = f->params;
     o.count = f->count, o.momentum = f->momentum, o.eps = f->eps;
+    o.shift = f->shift, o.shift_out = f->shift_next;
     return 0;
 }
 
@@ -413,6 +414,7 @@ static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const 
     halo_fill(p, d, dgrad);
     p.src = (const bf16*)src, p.wgt = (const bf16*)w, p.out = (bf16*)out;
     p.stats = stats;
+    p.stat_shift = (stats != nullptr && fin != nullptr) ? fin->shift : nullptr;
     p.accumulate = accumulate;
     const size_t out_e = (size_t)p.NP * p.H * p.W * p.Cn;
     const int nchunks = p.Cs / plan.CK;
@@ -436,7 +438,7 @@ static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const 
     int rc = vc_launch_halo(p, plan, S(stream));
     if (rc || fin == nullptr || stats == nullptr) return rc;
     return vc_ew_bn_finalize(stats, p.Cn, fin->count, fin->gamma, fin->beta, fin->running_mean, fin->running_var,
-                             fin->momentum, fin->eps, fin->params, S(stream));
+                             fin->momentum, fin->eps, fin->params, fin->shift, fin->shift_out, S(stream));
 }
 
 extern "C" {
@@ -775,7 +777,7 @@ static int stem_fwd_impl(const void* xs, const void* ws, void* y, float* bn_stat
         }
         if (fin == nullptr || bn_stats == nullptr) return 0;
         return vc_ew_bn_finalize(bn_stats, Co, fin->count, fin->gamma, fin->beta, fin->running_mean, fin->running_var,
-                                 fin->momentum, fin->eps, fin->params, S(stream));
+                                 fin->momentum, fin->eps, fin->params, fin->shift, fin->shift_out, S(stream));
     }
     int M, Ho, Wo, Tp, Hp, Wp;
     stem_geometry(N, T, H, W, M, Ho, Wo, Tp, Hp, Wp);
@@ -785,7 +787,8 @@ static int stem_fwd_impl(const void* xs, const void* ws, void* y, float* bn_stat
         sp.ws = (const bf16*)ws;
         sp.y = (bf16*)y;
         sp.stats = bn_stats;
-        if (fin != nullptr && bn_stats != nullptr) sp.fin = *fin;
+        sp.stat_shift = nullptr;
+        if (fin != nullptr && bn_stats != nullptr) sp.fin = *fin, sp.stat_shift = fin->shift;
         return vc_launch_stem_fwd(sp, S(stream));
     }
     VcIgemmParams p;
@@ -803,7 +806,7 @@ static int stem_fwd_impl(const void* xs, const void* ws, void* y, float* bn_stat
     p.Kw = 1344;
     p.Cn = Co;
     p.out_w = Co, p.out_h = Wo * Co, p.out_t = Ho * Wo * Co, p.out_n = T * Ho * Wo * Co, p.out_base = 0;
-    if (fin != nullptr && bn_stats != nullptr) p.fin = *fin;
+    if (fin != nullptr && bn_stats != nullptr) p.fin = *fin, p.stat_shift = fin->shift;
     return vc_launch_igemm(p, 1, S(stream));
 }
 int vc_stem_fwd(const void* xs, const void* ws, void* y, float* bn_stats, int32_t N, int32_t T, int32_t H, int32_t W,
@@ -881,16 +884,18 @@ int vc_stem_unpack_wgrad(const float* dws, float* dw_master, int32_t Co, void* s
 }
 
 /* ------------------------------------------------------------------ batch norm */
-int vc_bn_stats(const void* y, float* sums, int64_t rows, int32_t C, void* stream) {
+int vc_bn_stats(const void* y, float* sums, float* shift_out, int64_t rows, int32_t C, void* stream) {
     VC_REQUIRE(y && sums && rows > 0, "bn_stats: bad arguments");
     VC_REQUIRE(pow2_channels(C), "bn: C=%d must be a power of two in [64, 2048]", C);
-    return vc_ew_bn_stats(y, sums, rows, C, nullptr, S(stream));
+    return vc_ew_bn_stats(y, sums, rows, C, shift_out, S(stream));
 }
 int vc_bn_finalize(const float* stats, int32_t C, float count, const float* gamma, const float* beta,
-                   float* running_mean, float* running_var, float momentum, float eps, float* params, void* stream) {
+                   float* running_mean, float* running_var, float momentum, float eps, float* params,
+                   const float* shift, float* shift_next, void* stream) {
     VC_REQUIRE(stats && gamma && beta && params && C > 0 && count > 0, "bn_finalize: bad arguments");
     VC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
-    return vc_ew_bn_finalize(stats, C, count, gamma, beta, running_mean, running_var, momentum, eps, params, S(stream));
+    return vc_ew_bn_finalize(stats, C, count, gamma, beta, running_mean, running_var, momentum, eps, params, shift, shift_next,
+                             S(stream));
 }
 int vc_bn_eval_params(int32_t C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* params, void* stream) {

@@ -10,12 +10,14 @@ struct VcPoolGeom {
 };
 
 int vc_ew_bn_finalize(const float* stats, int C, float count, const float* gamma, const float* beta, float* rmean,
-                      float* rvar, float momentum, float eps, float* params, hipStream_t s);
+                      float* rvar, float momentum, float eps, float* params, const float* shift, float* shift_out,
+                      hipStream_t s);
 int vc_ew_bn_eval_params(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
                          float* params, hipStream_t s);
 int vc_ew_bn_apply(const void* y, const float* params, const void* res, void* out, long n, int C, int relu,
                    hipStream_t s);
-int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, const VcBnFin* fin, hipStream_t s);
+// shift_out (nullable): the sums are taken relative to row 0 of y, which is written there for the finalize
+int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, float* shift_out, hipStream_t s);
 int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums, long rows,
                         int C, int mask, const VcBnBwdFin* fin, hipStream_t s);
 int vc_ew_bn_bwd_finalize(const float* sums, int C, float count, float* coef, float* dgamma, float* dbeta,

@@ -24,10 +24,11 @@ __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
 // stats [R][2][C] (sum, sumsq) -> params [4][C] = mean, invstd, scale, shift; running stats.
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, float count, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum,
-                                   float eps, float* params) {
+                                   float eps, float* params, const float* shift, float* shift_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    vc_bn_finalize_channel<false>(stats, C, c, count, gamma, beta, running_mean, running_var, momentum, eps, params);
+    vc_bn_finalize_channel<false>(stats, C, c, count, gamma, beta, running_mean, running_var, momentum, eps, params, shift,
+                                  shift_out);
 }
 
 // eval mode: params from running statistics
@@ -92,7 +93,8 @@ template <int MODE, int MASK>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restrict__ y, const bf16x8* __restrict__ dz,
                                                           const bf16x8* __restrict__ aux,
                                                           const float* __restrict__ params, float* sums, long rows,
-                                                          int C, int CS, VcBnFin ffin, VcBnBwdFin bfin) {
+                                                          int C, int CS, VcBnFin ffin, VcBnBwdFin bfin,
+                                                          float* shift_out) {
     __shared__ float sm[256 * 17];
     const int groups = C >> 3;             // 8-channel groups per row
     const int cs = blockIdx.x % CS;        // channel slice: groups [8cs, 8cs + 8)
@@ -104,6 +106,17 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restri
 #pragma unroll
     for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
     float mean[8], invstd[8], scale[8], shift[8];
+    float sh0[8];  // MODE 0 with shift_out: the sums are taken relative to row 0 of y (within a few sigma of the mean
+                   // of any channel, and known to every block without a pass of its own); written out for the finalize
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh0[k] = 0.f;
+    if (MODE == 0 && shift_out != nullptr) {
+        unpack8(y[g], sh0);
+        if (rs == 0 && r == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) shift_out[g * 8 + k] = sh0[k];
+        }
+    }
     if (MODE == 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -120,8 +133,9 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restri
         if (MODE == 0) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                a0[k] += f[k];
-                a1[k] += f[k] * f[k];
+                const float u = f[k] - sh0[k];
+                a0[k] += u;
+                a1[k] += u * u;
             }
         } else {
             float d[8], m[8];
@@ -163,16 +177,19 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ slabs, int splits,
                                                               long long stride, bf16x8* __restrict__ out,
                                                               int accumulate, float* stats, long rows, int C,
-                                                              int CS, VcBnFin fin) {
+                                                              int CS, VcBnFin fin, const float* stat_shift) {
     // same decomposition as chan_reduce_kernel: 64-channel slice x row phase (float atomics per launch = RS x 2C)
     __shared__ float sm[STATS ? 256 * 17 : 1];
     const int groups = C >> 3;
     const int cs = blockIdx.x % CS, rs = blockIdx.x / CS, RS = gridDim.x / CS;
     const int g = cs * 8 + (threadIdx.x & 7);
     const int r = threadIdx.x >> 3;
-    float a0[8], a1[8];
+    float a0[8], a1[8], sh0[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
+    for (int k = 0; k < 8; ++k) {
+        a0[k] = a1[k] = 0.f;
+        sh0[k] = (STATS && stat_shift != nullptr) ? stat_shift[g * 8 + k] : 0.f;  // shifted sums (bn_fin.h)
+    }
     for (long row = (long)rs * 32 + r; row < rows; row += (long)RS * 32) {
         const long i = row * groups + g;
         float v[8];
@@ -197,8 +214,9 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
         if (STATS) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                a0[k] += v[k];
-                a1[k] += v[k] * v[k];
+                const float u = v[k] - sh0[k];
+                a0[k] += u;
+                a1[k] += u * u;
             }
         }
     }
@@ -1020,9 +1038,10 @@ static inline int vc_check_launch() {
 #define VC_CHECK_LAUNCH() vc_check_launch()
 
 int vc_ew_bn_finalize(const float* stats, int C, float count, const float* gamma, const float* beta, float* rmean,
-                      float* rvar, float momentum, float eps, float* params, hipStream_t s) {
+                      float* rvar, float momentum, float eps, float* params, const float* shift, float* shift_out,
+                      hipStream_t s) {
     VC_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, C, count, gamma, beta, rmean,
-                       rvar, momentum, eps, params);
+                       rvar, momentum, eps, params, shift, shift_out);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_eval_params(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
@@ -1060,12 +1079,12 @@ static void chan_reduce_geometry(long rows, int C, int& grid, int& CS) {
     if (RS < 1) RS = 1;
     grid = (int)(RS * CS);
 }
-int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, const VcBnFin* fin, hipStream_t s) {
+int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, float* shift_out, hipStream_t s) {
     int grid, slices;
     chan_reduce_geometry(rows, C, grid, slices);
     VC_LAUNCH((chan_reduce_kernel<0, 0>), dim3(grid), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)nullptr,
-                       (const bf16x8*)nullptr, (const float*)nullptr, sums, rows, C, slices, fin ? *fin : VcBnFin{},
-                       VcBnBwdFin{});
+                       (const bf16x8*)nullptr, (const float*)nullptr, sums, rows, C, slices, VcBnFin{}, VcBnBwdFin{},
+                       shift_out);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums, long rows,
@@ -1076,13 +1095,13 @@ int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const fl
     const VcBnBwdFin bf = fin ? *fin : VcBnBwdFin{};
     if (mask == 0)
         VC_LAUNCH((chan_reduce_kernel<1, 0>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
-                  VcBnFin{}, bf);
+                  VcBnFin{}, bf, (float*)nullptr);
     else if (mask == 1)
         VC_LAUNCH((chan_reduce_kernel<1, 1>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
-                  VcBnFin{}, bf);
+                  VcBnFin{}, bf, (float*)nullptr);
     else
         VC_LAUNCH((chan_reduce_kernel<1, 2>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
-                  VcBnFin{}, bf);
+                  VcBnFin{}, bf, (float*)nullptr);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void* out, int accumulate, float* stats,
@@ -1091,10 +1110,10 @@ int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void
     chan_reduce_geometry(rows, C, grid, slices);
     if (stats)
         VC_LAUNCH((splitk_finalize_kernel<true>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
-                  accumulate, stats, rows, C, slices, fin ? *fin : VcBnFin{});
+                  accumulate, stats, rows, C, slices, fin ? *fin : VcBnFin{}, fin ? fin->shift : (const float*)nullptr);
     else
         VC_LAUNCH((splitk_finalize_kernel<false>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
-                  accumulate, stats, rows, C, slices, VcBnFin{});
+                  accumulate, stats, rows, C, slices, VcBnFin{}, (const float*)nullptr);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, int Ci, int taps,

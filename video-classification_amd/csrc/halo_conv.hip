@@ -516,12 +516,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (p.stats != nullptr) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
+            f32x4 sh4 = {0.f, 0.f, 0.f, 0.f};  // shifted sums (bn_fin.h)
+            if (p.stat_shift != nullptr) sh4 = *(const f32x4*)(p.stat_shift + cobase + a * 16);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float ss = 0.f, qq = 0.f;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    const float v = ooff[b] >= 0 ? acc[a][b][j] : 0.f;
+                    const float v = ooff[b] >= 0 ? acc[a][b][j] - sh4[j] : 0.f;
                     ss += v;
                     qq += v * v;
                 }

@@ -128,11 +128,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
     // BatchNorm statistics: per-lane partial sums over this workgroup's tiles, reduced across lanes and added to
     // the replicated accumulators once, after the tile loop (device-scope float atomics are the expensive part:
     // one set per tile held a 64 -> 256 pointwise conv to half its bandwidth)
-    float st_s[4][4], st_q[4][4];
+    float st_s[4][4], st_q[4][4], st_h[4][4];  // st_h: the shift of the sums (bn_fin.h), 0 without one
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st_s[a][j] = 0.f, st_q[a][j] = 0.f;
+        for (int j = 0; j < 4; ++j) {
+            st_s[a][j] = 0.f, st_q[a][j] = 0.f;
+            st_h[a][j] = (p.stats != nullptr && p.stat_shift != nullptr) ? p.stat_shift[cobase + a * 16 + j] : 0.f;
+        }
 
     // A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the host caps gridDim.x for single-geometry
     // launches so that all workgroups are resident and own the same number of tiles).
@@ -264,14 +267,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
                     }
             }
         }
-        if (p.stats != nullptr) {  // rows beyond M hold exact zeros
+        if (p.stats != nullptr) {  // rows beyond M hold exact zeros, which a shift would turn into -shift: skipped
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const float v = acc[a][b][j];
+                        const float v = ooff[b] >= 0 ? acc[a][b][j] - st_h[a][j] : 0.f;
                         st_s[a][j] += v;
                         st_q[a][j] += v * v;
                     }

@@ -8,6 +8,7 @@ struct VcIgemmParams {
     const bf16* wgt;  // [Cn][Kw]
     bf16* out;
     float* stats;  // nullable: [VC_STAT_REPLICAS][2][Cn]
+    const float* stat_shift;  // nullable: [Cn], subtracted from every value before it enters the sums (bn_fin.h)
     VcBnFin fin;   // fin.ticket nullable: the last workgroup finalizes the BatchNorm parameters (bn_fin.h)
     const float* ep_params;  // nullable: BatchNorm params [4][Cn] applied in the epilogue (out = scale * acc + shift)
     int ep_relu;             // ... followed by ReLU
@@ -58,6 +59,7 @@ struct VcHaloParams {
     const bf16* wgt;  // [Cn][Kw]
     bf16* out;        // [NP*H*W][Cn]
     float* stats;     // nullable: [VC_STAT_REPLICAS][2][Cn]
+    const float* stat_shift;  // nullable: [Cn], subtracted from every value before it enters the sums (bn_fin.h)
     VcBnFin fin;      // fin.ticket nullable: the last workgroup finalizes the BatchNorm parameters (bn_fin.h)
     const float* ep_params;  // nullable: BatchNorm params [4][Cn] applied in the epilogue (out = scale * acc + shift)
     int ep_relu;             // ... followed by ReLU
@@ -120,6 +122,7 @@ struct VcStemFwdParams {
     const bf16* ws;  // [64][1344]
     bf16* y;         // [N*T*Ho*Wo][64]
     float* stats;    // nullable: [VC_STAT_REPLICAS][2][64]
+    const float* stat_shift;  // nullable: [64], subtracted from every value before it enters the sums (bn_fin.h)
     VcBnFin fin;     // fin.ticket nullable: the last workgroup finalizes the BatchNorm parameters (bn_fin.h)
     int N, T, Ho, Wo, Tp, Hp, Wp;
     int RH;          // output rows per chunk (RH * Wo <= 224)

@@ -103,6 +103,8 @@ def main(argv=None):
         ck = torch.load(resume, map_location='cpu', weights_only=True)
         model.load_state_dict({(k[7:] if k.startswith('module.') else k): v for k, v in ck['state_dict'].items()})
         optimizer.load_state_dict(ck['optimizer'])
+        if 'engine' in ck:
+            model.backbone.engine.load_state_dict(ck['engine'])
         lr_scheduler.load_state_dict(ck['lr_scheduler'])
         best_perf = float(ck.get('best_perf', -1.0))
         begin_epoch = max(begin_epoch, int(ck['epoch']) + 1)
@@ -121,7 +123,8 @@ def main(argv=None):
                 logger.info('=> saved best model (top-1 %.4f) to %s', best_perf, path)
         if rank == 0:
             torch.save({'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict(),
-                        'lr_scheduler': lr_scheduler.state_dict(), 'epoch': epoch, 'best_perf': best_perf}, ckpt_path)
+                        'lr_scheduler': lr_scheduler.state_dict(), 'epoch': epoch, 'best_perf': best_perf,
+                        'engine': model.backbone.engine.state_dict()}, ckpt_path)
     if world > 1:
         dist.destroy_process_group()
     return best_perf

@@ -48,7 +48,7 @@ class BnFin(C.Structure):
     """vc_bn_fin: BatchNorm finalize folded into the launch that produces the sums (include/vc3d.h)."""
     _fields_ = [("ticket", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
                 ("running_var", C.c_void_p), ("params", C.c_void_p), ("count", C.c_float), ("momentum", C.c_float),
-                ("eps", C.c_float)]
+                ("eps", C.c_float), ("shift", C.c_void_p), ("shift_next", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -86,8 +86,8 @@ PROTOTYPES = {
     "vc_stem_wgrad_workspace_bytes": [_I, _I, _I, _I, _I],
     "vc_stem_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P, C.c_size_t, _P],
     "vc_stem_unpack_wgrad": [_P, _P, _I, _P],
-    "vc_bn_stats": [_P, _P, _L, _I, _P],
-    "vc_bn_finalize": [_P, _I, _F, _P, _P, _P, _P, _F, _F, _P, _P],
+    "vc_bn_stats": [_P, _P, _P, _L, _I, _P],
+    "vc_bn_finalize": [_P, _I, _F, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P],
     "vc_bn_eval_params": [_I, _P, _P, _P, _P, _F, _P, _P],
     "vc_bn_apply": [_P, _P, _P, _P, _L, _I, _I, _P],
     "vc_bn_bwd_reduce": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
@@ -122,7 +122,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.vc_abi_version() != 1:
+    if lib.vc_abi_version() != 2:
         raise Vc3dError("libvc3d.so ABI version mismatch")
     return lib
 

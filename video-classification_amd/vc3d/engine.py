@@ -22,6 +22,7 @@ F32 = torch.float32
 FUSED_EVAL_ACT = os.environ.get("VC_NO_EVAL_ACT") is None  # inference: BatchNorm + ReLU in the conv epilogue
 FUSED_BN_FIN = os.environ.get("VC_NO_BN_FIN") is None  # BatchNorm finalize done by the last workgroup of the producer
 SIDE_WGRAD = os.environ.get("VC_WGRAD_SIDE_STREAM", "1") != "0"  # weight gradients on a side stream (engine._wgrad)
+FIRST_STATS = os.environ.get("VC_FIRST_STATS") is not None  # stand-alone row-0-shifted statistics on a layer's first step
 
 
 def _triple(v):
@@ -39,6 +40,8 @@ class _ConvBN:
         self.wver = -1
         self.eval_params = None
         self.eval_ver = None
+        self.shift = None         # [Co] fp32: what the BatchNorm sums are taken relative to = the previous batch mean
+        self.shift_valid = False  # False until a first robust estimate exists (engine._first_stats)
 
     def desc(self, x):
         N, T, H, W, C = x.shape
@@ -93,6 +96,12 @@ class R3DEngine:
         self._tickets = None       # zero int32 words of the fused BatchNorm finalize (see _ticket)
         self._ticket_ix = None
         self.trace = None  # tests set this to {} to record every intermediate tensor per layer
+        # BatchNorm sums are taken relative to the previous batch mean (cb.shift).  On a layer's FIRST training step no
+        # such estimate exists: by default the fused sums run with a zero shift (the textbook one-pass form on the fp32
+        # accumulators: exact to 1e-5 for |mean| <= 10 sigma, and a bf16 tensor with |mean| = 100 sigma has lost its
+        # content to storage rounding anyway); True (VC_FIRST_STATS=1): that one step takes a stand-alone pass over the
+        # stored bf16 tensor relative to its row 0 instead (robust at any ratio, but it sees the rounded values)
+        self.first_stats = FIRST_STATS
 
     def _t(self, name, **kw):
         if self.trace is not None:
@@ -265,10 +274,36 @@ class R3DEngine:
             raise Vc3dError("cumulative-average BatchNorm (momentum=None) is not supported")
         fin, p = ops.bn_fin(self._ticket(cb, False), count, bn.weight.detach(), bn.bias.detach(),
                             bn.running_mean if bn.track_running_stats else None,
-                            bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps)
+                            bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps,
+                            shift=self._shift(cb))
         if bn.track_running_stats and bn.num_batches_tracked is not None:
             self._nbt.append(bn.num_batches_tracked)
         return fin, p
+
+    def _shift(self, cb):
+        dev = cb.bn.weight.device
+        if cb.shift is None or cb.shift.device != dev:
+            cb.shift = torch.zeros(cb.Co, dtype=F32, device=dev)
+            cb.shift_valid = False
+        return cb.shift
+
+    def _first_stats(self, cb, y, stats, count):
+        """BatchNorm statistics of a layer that has no shift yet (first training step, or a new device): one extra pass
+        over y whose sums are taken relative to row 0 of y (vc_bn_stats), so that the very first batch is as robust
+        against |mean| >> sigma as the later ones, whose fused sums are relative to the previous batch mean."""
+        bn = cb.bn
+        if bn.momentum is None:
+            raise Vc3dError("cumulative-average BatchNorm (momentum=None) is not supported")
+        shift = self._shift(cb)
+        ops.bn_stats(y, cb.Co, sums=stats, shift=shift)
+        p = ops.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(),
+                            bn.running_mean if bn.track_running_stats else None,
+                            bn.running_var if bn.track_running_stats else None, bn.momentum, bn.eps, shift=shift,
+                            shift_next=shift)
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            self._nbt.append(bn.num_batches_tracked)
+        cb.shift_valid = True
+        return p
 
     def _bn_params(self, cb, stats, count, training):
         bn = cb.bn
@@ -297,6 +332,10 @@ class R3DEngine:
         stats = stats_pool.take(cb.Co) if training else None
         To, Ho, Wo = d.out_dims()
         count = d.N * To * Ho * Wo
+        if training and FUSED_BN_FIN and self.first_stats and not (cb.shift_valid and cb.shift is not None
+                                                                     and cb.shift.device == x.device):
+            y = ops.conv3d_fwd(d, x, wf)
+            return d, y, self._first_stats(cb, y, stats, count)
         fin, params = self._bn_fin(cb, count) if training else (None, None)
         y = ops.conv3d_fwd(d, x, wf, stats=stats, fin=fin)
         if fin is None:
@@ -316,6 +355,18 @@ class R3DEngine:
         except Vc3dError:
             self._reset_tickets()
             raise
+
+    def state_dict(self):
+        """engine state that is not a module parameter or buffer: the BatchNorm shifts.  Saved by train.py so that a
+        resumed run takes its sums relative to the same values as the uninterrupted one (bit-for-bit continuation)."""
+        return {"bn_shift": [None if cb.shift is None else cb.shift.detach().cpu().clone() for cb in self.all_convbn()]}
+
+    def load_state_dict(self, sd):
+        dev = self.stem.bn.weight.device
+        for cb, t in zip(self.all_convbn(), sd.get("bn_shift", [])):
+            if t is not None:
+                cb.shift = t.to(device=dev, dtype=F32).clone()
+                cb.shift_valid = True
 
     def _reset_tickets(self):
         """a launch that failed midway may leave ticket words of the fused BatchNorm finalize non-zero (they are only
@@ -347,10 +398,15 @@ class R3DEngine:
             self.stem_wver = (w._version, self.param_epoch)
         xs = x.xs if packed else ops.stem_pack_input(x)
         stats0 = stats_pool.take(st.Co) if training else None
-        fin0, p0 = self._bn_fin(st, N * T * (H // 2) * (W // 2)) if training else (None, None)
-        y0 = ops.stem_fwd(xs, self.stem_ws, N, T, H, W, st.Co, stats=stats0, fin=fin0)
-        if fin0 is None:
-            p0 = self._bn_params(st, stats0, y0.numel() // st.Co, training)
+        if training and FUSED_BN_FIN and self.first_stats and not (st.shift_valid and st.shift is not None
+                                                                     and st.shift.device == dev):
+            y0 = ops.stem_fwd(xs, self.stem_ws, N, T, H, W, st.Co)
+            p0 = self._first_stats(st, y0, stats0, y0.numel() // st.Co)
+        else:
+            fin0, p0 = self._bn_fin(st, N * T * (H // 2) * (W // 2)) if training else (None, None)
+            y0 = ops.stem_fwd(xs, self.stem_ws, N, T, H, W, st.Co, stats=stats0, fin=fin0)
+            if fin0 is None:
+                p0 = self._bn_params(st, stats0, y0.numel() // st.Co, training)
         pk, ps, pp = self.pool
         pd = ops.pool_desc(N, st.Co, T, H // 2, W // 2, pk, ps, pp)
         a0, idx = ops.maxpool3d_fwd(pd, y0, p0)

@@ -108,7 +108,7 @@ def pack_weight(w_master, want_dgrad=True):
     return wf, wd
 
 
-def bn_fin(ticket, count, gamma, beta, running_mean, running_var, momentum, eps, params=None):
+def bn_fin(ticket, count, gamma, beta, running_mean, running_var, momentum, eps, params=None, shift=None):
     """descriptor of a BatchNorm finalize folded into the conv launch that produces the sums (the last workgroup
     does bn_finalize's work).  `ticket`: capi.VC_TICKET_WORDS int32 words, zero before their first use (left zero by the launch).
     Returns (descriptor, params [4][C])."""
@@ -119,9 +119,10 @@ def bn_fin(ticket, count, gamma, beta, running_mean, running_var, momentum, eps,
     if params is None:
         params = torch.empty(4, Cn, dtype=F32, device=gamma.device)
     _chk(params, F32, 4 * Cn, "bn params")
+    _chk(shift, F32, Cn, "bn shift")  # sums relative to it; receives this batch's mean (the next step's shift)
     f = capi.BnFin(ptr(ticket), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(params), float(count),
-                   float(momentum), float(eps))
-    f._keep = (ticket, gamma, beta, running_mean, running_var, params)
+                   float(momentum), float(eps), ptr(shift), ptr(shift))
+    f._keep = (ticket, gamma, beta, running_mean, running_var, params, shift)
     return f, params
 
 
@@ -324,17 +325,21 @@ def stem_wgrad(xs, dy, N, T, H, W, Co, dw_master_phys, scratch=None):
 
 
 # ------------------------------------------------------------------ batch norm
-def bn_stats(y, C, sums=None):
+def bn_stats(y, C, sums=None, shift=None):
+    """shift ([C] fp32, optional): the kernel takes the sums relative to row 0 of y and writes that row there; hand the
+    same tensor to bn_finalize (robust against |mean| >> sigma)."""
     _chk(y, BF16, name="y")
     rows = y.numel() // C
     if sums is None:
         sums = new_stats(C, y.device)
     _chk(sums, F32, VC_STAT_REPLICAS * 2 * C, "sums")
-    check(lib.vc_bn_stats(ptr(y), ptr(sums), rows, C, cur_stream()), "vc_bn_stats")
+    _chk(shift, F32, C, "bn shift")
+    check(lib.vc_bn_stats(ptr(y), ptr(sums), ptr(shift), rows, C, cur_stream()), "vc_bn_stats")
     return sums
 
 
-def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, params=None):
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, params=None, shift=None,
+                shift_next=None):
     Cn = gamma.numel()
     _chk(stats, F32, VC_STAT_REPLICAS * 2 * Cn, "stats")
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
@@ -342,9 +347,11 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
     if params is None:
         params = torch.empty(4, Cn, dtype=F32, device=gamma.device)
     _chk(params, F32, 4 * Cn, "bn params")
+    _chk(shift, F32, Cn, "bn shift")
+    _chk(shift_next, F32, Cn, "bn shift_next")
     check(lib.vc_bn_finalize(ptr(stats), Cn, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
-                             ptr(running_var), float(momentum), float(eps), ptr(params), cur_stream()),
-          "vc_bn_finalize")
+                             ptr(running_var), float(momentum), float(eps), ptr(params), ptr(shift), ptr(shift_next),
+                             cur_stream()), "vc_bn_finalize")
     return params
 
 
