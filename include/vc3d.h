@@ -220,6 +220,17 @@ int vc_linear_bwd(const float* dlogits, const float* feat, const float* W, float
                   float* dW /* += nullable */, float* db /* += nullable */, int32_t N, int32_t F,
                   int32_t K, void* stream);
 
+/* ---- LSTM cell.  Replaces nn.LSTMCell at reference lib/models/lstm.py:16,25-27.  The cell's two
+ * GEMMs, gates[N][4H] = [x h] [W_ih W_hh]^T, are a 1x1x1 conv over N positions (vc_conv3d_fwd / _dgrad / _wgrad with
+ * T = H = W = 1, Ci = Fin + H, Co = 4H; bf16 MFMA).  These two calls are the element-wise rest, one pass each way.
+ * gates / dgates: bf16 [N][4H], torch's gate order i, f, g, o.  saved: fp32 [N][5H] = the four activations and
+ * tanh(c').  h_bf16 (nullable): h' once more in bf16, the next step's GEMM operand.  Backward: dh and dc_next are the
+ * gradients of h' and c' (either nullable); db_ih / db_hh (nullable) are accumulated into (+=). */
+int vc_lstm_pointwise_fwd(const void* gates, const float* b_ih, const float* b_hh, const float* c_prev, float* h, float* c,
+                          void* h_bf16, float* saved, int32_t N, int32_t H, void* stream);
+int vc_lstm_pointwise_bwd(const float* dh, const float* dc_next, const float* saved, const float* c_prev, void* dgates,
+                          float* dc_prev, float* db_ih, float* db_hh, int32_t N, int32_t H, void* stream);
+
 /* ---- Layout helpers at the API edge (NCTHW <-> NTHWC). */
 int vc_ncthw_to_nthwc(const void* in, int32_t in_is_bf16, void* out, int32_t N, int32_t C, int64_t S,
                       void* stream);

@@ -1037,6 +1037,18 @@ int vc_linear_bwd(const float* dlogits, const float* feat, const float* W, float
     return vc_ew_linear_bwd(dlogits, feat, W, dfeat, dW, db, N, F, K, S(stream));
 }
 
+/* ------------------------------------------------------------------ LSTM cell (element-wise half) */
+int vc_lstm_pointwise_fwd(const void* gates, const float* b_ih, const float* b_hh, const float* c_prev, float* h, float* c,
+                          void* h_bf16, float* saved, int32_t N, int32_t H, void* stream) {
+    VC_REQUIRE(gates && b_ih && b_hh && c_prev && h && c && N > 0 && H > 0, "lstm_pointwise_fwd: bad arguments");
+    return vc_ew_lstm_pointwise_fwd(gates, b_ih, b_hh, c_prev, h, c, h_bf16, saved, N, H, S(stream));
+}
+int vc_lstm_pointwise_bwd(const float* dh, const float* dc_next, const float* saved, const float* c_prev, void* dgates,
+                          float* dc_prev, float* db_ih, float* db_hh, int32_t N, int32_t H, void* stream) {
+    VC_REQUIRE(saved && c_prev && dgates && (dh || dc_next) && N > 0 && H > 0, "lstm_pointwise_bwd: bad arguments");
+    return vc_ew_lstm_pointwise_bwd(dh, dc_next, saved, c_prev, dgates, dc_prev, db_ih, db_hh, N, H, S(stream));
+}
+
 /* ------------------------------------------------------------------ layout */
 int vc_ncthw_to_nthwc(const void* in, int32_t in_is_bf16, void* out, int32_t N, int32_t C, int64_t Sp, void* stream) {
     VC_REQUIRE(in && out && N > 0 && C > 0 && Sp > 0, "ncthw_to_nthwc: bad arguments");

@@ -12,6 +12,11 @@ struct VcPoolGeom {
 int vc_ew_bn_finalize(const float* stats, int C, float count, const float* gamma, const float* beta, float* rmean,
                       float* rvar, float momentum, float eps, float* params, const float* shift, float* shift_out,
                       hipStream_t s);
+// lstm.hip
+int vc_ew_lstm_pointwise_fwd(const void* gates, const float* b_ih, const float* b_hh, const float* c_prev, float* h, float* c,
+                             void* h_bf16, float* saved, int N, int H, hipStream_t s);
+int vc_ew_lstm_pointwise_bwd(const float* dh, const float* dc_next, const float* saved, const float* c_prev, void* dgates,
+                             float* dc_prev, float* db_ih, float* db_hh, int N, int H, hipStream_t s);
 int vc_ew_bn_eval_params(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
                          float* params, hipStream_t s);
 int vc_ew_bn_apply(const void* y, const float* params, const void* res, void* out, long n, int C, int relu,

@@ -43,6 +43,9 @@ config.MODEL.PRETRAINED_PATH = 'pretrained_models/?'
 config.MODEL.CLIP_LEN = 16
 config.MODEL.CROP_SIZE = 112
 config.MODEL.DTYPE = 'bf16'
+# the reference's recurrent head (lstm.py, model.py:18-25): backbone features -> LSTMCell -> action / class / critic heads.
+# Off by default: north_star's hot path is the 3D backbone with a plain classifier head.
+config.MODEL.USE_LSTM = False
 # raw-frame input (uint8 N x Ts x Hs x Ws x 3 from a decoder): sampling / normalisation done on the GPU by
 # utils.ChooseInput -> vc_clip_pack_u8; mean / std in units of u8 / 255
 config.MODEL.FRAME_STEP = 1
@@ -62,6 +65,7 @@ config.TRAIN.R_ACT = 1
 config.TRAIN.R_CRT = 1
 config.TRAIN.TRAIN_STEP = 10
 config.TRAIN.ROLLOUT_STEP = 1
+config.TRAIN.GAMMA = 0.99  # discount of the one-step advantage in utils.rollout
 config.TRAIN.BEGIN_EPOCH = 0
 config.TRAIN.END_EPOCH = 100
 config.TRAIN.BATCH_SIZE = 32

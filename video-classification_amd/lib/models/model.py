@@ -20,13 +20,32 @@ class VedioClfNet(nn.Module):
     def __init__(self, config, is_train=True):
         super().__init__()
         self.backbone = getBackbone(config, is_train)
-        self.clf_haed = nn.Linear(self.backbone.out_features, config.MODEL.CLFDIM)
+        self.use_lstm = bool(config.MODEL.get("USE_LSTM", False))
+        if self.use_lstm:
+            # the reference's recurrent head (model.py:18-25): LSTM -> act_head (Linear + Sigmoid), clf_haed, crit_head
+            from models.lstm import getLSTM
+            hid = config.MODEL.LSTM_OUTDIM
+            self.lstm = getLSTM(config, in_dim=self.backbone.out_features)
+            self.act_head = nn.Sequential(nn.Linear(hid, 1), nn.Sigmoid())
+            self.clf_haed = nn.Linear(hid, config.MODEL.CLFDIM)
+            self.crit_head = nn.Linear(hid, 1)
+        else:
+            self.clf_haed = nn.Linear(self.backbone.out_features, config.MODEL.CLFDIM)
 
     def features(self, x):
         return self.backbone(x)
 
     def forward(self, x):
         eng = self.backbone.engine
+        if self.use_lstm:
+            # reference model.py:35-41: x -> backbone -> lstm -> three heads; every Linear is the vc3d fp32 head kernel
+            eng.head_params = ()
+            h = self.lstm(self.backbone(x))
+            a0 = self.act_head[0]
+            action = torch.sigmoid(vc3d.linear_apply(h, a0.weight, a0.bias))
+            score = vc3d.linear_apply(h, self.clf_haed.weight, self.clf_haed.bias)
+            value = vc3d.linear_apply(h, self.crit_head.weight, self.crit_head.bias)
+            return action, score, value
         eng.head_params = (self.clf_haed.weight, self.clf_haed.bias)
         feat = self.backbone(x)
         score = vc3d.linear_apply(feat, self.clf_haed.weight, self.clf_haed.bias, eng)

@@ -25,6 +25,7 @@ def create_optimizer(cfg, model):
 def _fusable(model):
     core = model.module if hasattr(model, "module") else model
     return (hasattr(core, "backbone") and hasattr(core.backbone, "engine") and hasattr(core, "clf_haed")
+            and not getattr(core, "use_lstm", False)  # the LSTM / actor / critic parameters live outside the flat buffer
             and all(p.is_cuda for p in core.parameters()))
 
 
@@ -76,9 +77,33 @@ def ChooseInput(vedio, action, step=0, nsteps=1):
 
 
 def rollout(vedio, model, action, value):
-    """reference utils.py:67-80 is an empty stub.  Returns (log_prob, advantages) = (None, None):
-    no actor/critic terms, so Loss reduces to cross-entropy."""
-    return None, None
+    """reference utils.py:67-80 is an empty stub ("rollout according to model's policy ... lists of log_prob and
+    advantages"); neither an environment nor a reward is defined upstream.  Without the recurrent head (the default)
+    this returns (None, None) and Loss reduces to cross-entropy.  With it (MODEL.USE_LSTM) the minimal well-defined
+    instance: the action head's output p is the probability of a Bernoulli action a ~ B(p), log_prob = log P(a) (N x 1,
+    differentiable in p); advantages = gamma * V' - V (N x 1, reward-free one-step TD) where V' is the critic's value
+    after TRAIN.ROLLOUT_STEP further steps of the policy under no_grad (the LSTM state is restored afterwards) and
+    V = `value` keeps its graph, so r_crt * mean(adv^2) trains the critic and the actor term sees adv.detach()
+    (reference loss.py:25-27)."""
+    core = model.module if hasattr(model, "module") else model
+    if not getattr(core, "use_lstm", False):
+        return None, None
+    from core.config import config as cfg
+    p = action.clamp(1e-6, 1.0 - 1e-6)
+    a = torch.bernoulli(p.detach())
+    log_prob = a * torch.log(p) + (1.0 - a) * torch.log(1.0 - p)
+    lstm = core.lstm
+    keep = (lstm.h, lstm.c)
+    was_training = core.training
+    core.eval()  # the look-ahead must not touch the BatchNorm running statistics
+    with torch.no_grad():
+        v_next = value.detach()
+        for _ in range(max(0, int(cfg.TRAIN.ROLLOUT_STEP))):
+            _, _, v_next = model(ChooseInput(vedio, a))
+    lstm.h, lstm.c = keep
+    core.train(was_training)
+    advantages = cfg.TRAIN.GAMMA * v_next.detach() - value
+    return log_prob, advantages
 
 
 def create_logger(cfg, phase='train'):

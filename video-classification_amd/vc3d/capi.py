@@ -105,6 +105,8 @@ PROTOTYPES = {
     "vc_gavgpool_bwd": [_P, _P, _I, _I, _I, _P],
     "vc_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vc_linear_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vc_lstm_pointwise_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "vc_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vc_ncthw_to_nthwc": [_P, _I, _P, _I, _I, _L, _P],
     "vc_nthwc_to_ncthw": [_P, _P, _I, _I, _I, _L, _P],
 }
