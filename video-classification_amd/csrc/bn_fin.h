@@ -128,16 +128,75 @@ __device__ __forceinline__ bool vc_last_workgroup(unsigned* ticket) {
     return s_last != 0u;
 }
 
+// The last workgroup's loops take VC_FIN_BATCH channels per thread at a time, every load of the batch issued before
+// the first use: one channel at a time is a chain of dependent ~2 us round trips below the L2 (8 of them for 2048
+// channels and 256 threads: +16 us on a 14 us layer4 pointwise conv), a batch is one.
+#define VC_FIN_BATCH 4
 __device__ __forceinline__ void vc_bn_fin_last(const VcBnFin& f, const float* stats, int C) {
     if (f.ticket == nullptr || stats == nullptr) return;
     if (!vc_last_workgroup(f.ticket)) return;
-    for (int c = threadIdx.x; c < C; c += blockDim.x)
-        vc_bn_finalize_channel<true>(stats, C, c, f.count, f.gamma, f.beta, f.running_mean, f.running_var, f.momentum,
-                                     f.eps, f.params, f.shift, f.shift_out);
+    const int step = (int)blockDim.x;
+    for (int base = (int)threadIdx.x; base < C; base += step * VC_FIN_BATCH) {
+        float s[VC_FIN_BATCH], q[VC_FIN_BATCH], g[VC_FIN_BATCH], b[VC_FIN_BATCH], rm[VC_FIN_BATCH], rv[VC_FIN_BATCH],
+            sh[VC_FIN_BATCH];
+#pragma unroll
+        for (int k = 0; k < VC_FIN_BATCH; ++k) {
+            const int c = base + k * step;
+            s[k] = q[k] = g[k] = b[k] = rm[k] = rv[k] = sh[k] = 0.f;
+            if (c < C) {
+                vc_stat_sum<true>(stats, C, c, s[k], q[k]);
+                g[k] = f.gamma[c], b[k] = f.beta[c];
+                if (f.running_mean != nullptr) rm[k] = f.running_mean[c], rv[k] = f.running_var[c];
+                if (f.shift != nullptr) sh[k] = f.shift[c];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VC_FIN_BATCH; ++k) {  // vc_bn_finalize_channel's arithmetic, on the values loaded above
+            const int c = base + k * step;
+            if (c >= C) continue;
+            const float m1 = s[k] / f.count;
+            const float mean = sh[k] + m1;
+            float var = q[k] / f.count - m1 * m1;
+            var = var > 0.f ? var : 0.f;
+            if (f.shift_out != nullptr) f.shift_out[c] = mean;
+            const float invstd = rsqrtf(var + f.eps);
+            const float scale = g[k] * invstd;
+            f.params[c] = mean;
+            f.params[C + c] = invstd;
+            f.params[2 * C + c] = scale;
+            f.params[3 * C + c] = b[k] - mean * scale;
+            if (f.running_mean != nullptr) {
+                const float unbiased = f.count > 1.f ? var * f.count / (f.count - 1.f) : var;
+                f.running_mean[c] = (1.f - f.momentum) * rm[k] + f.momentum * mean;
+                f.running_var[c] = (1.f - f.momentum) * rv[k] + f.momentum * unbiased;
+            }
+        }
+    }
 }
 __device__ __forceinline__ void vc_bn_bwd_fin_last(const VcBnBwdFin& f, const float* sums, int C) {
     if (f.ticket == nullptr || sums == nullptr) return;
     if (!vc_last_workgroup(f.ticket)) return;
-    for (int c = threadIdx.x; c < C; c += blockDim.x)
-        vc_bn_bwd_finalize_channel<true>(sums, C, c, f.count, f.coef, f.dgamma, f.dbeta);
+    const int step = (int)blockDim.x;
+    for (int base = (int)threadIdx.x; base < C; base += step * VC_FIN_BATCH) {
+        float s[VC_FIN_BATCH], q[VC_FIN_BATCH], dg[VC_FIN_BATCH], db[VC_FIN_BATCH];
+#pragma unroll
+        for (int k = 0; k < VC_FIN_BATCH; ++k) {
+            const int c = base + k * step;
+            s[k] = q[k] = dg[k] = db[k] = 0.f;
+            if (c < C) {
+                vc_stat_sum<true>(sums, C, c, s[k], q[k]);
+                if (f.dgamma != nullptr) dg[k] = f.dgamma[c];
+                if (f.dbeta != nullptr) db[k] = f.dbeta[c];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VC_FIN_BATCH; ++k) {
+            const int c = base + k * step;
+            if (c >= C) continue;
+            f.coef[c] = s[k] / f.count;
+            f.coef[C + c] = q[k] / f.count;
+            if (f.dgamma != nullptr) f.dgamma[c] = dg[k] + q[k];
+            if (f.dbeta != nullptr) f.dbeta[c] = db[k] + s[k];
+        }
+    }
 }
