@@ -130,11 +130,20 @@ __device__ __forceinline__ bool vc_last_workgroup(unsigned* ticket) {
 
 // The last workgroup's loops take VC_FIN_BATCH channels per thread at a time, every load of the batch issued before
 // the first use: one channel at a time is a chain of dependent ~2 us round trips below the L2 (8 of them for 2048
-// channels and 256 threads: +16 us on a 14 us layer4 pointwise conv), a batch is one.
-#define VC_FIN_BATCH 4
+// channels and 256 threads: +16 us on a 14 us layer4 pointwise conv), a batch is one.  A batch holds 16 loaded words per
+// channel: the GEMM kernels (register budget set by their accumulators) take four channels, the bandwidth kernels,
+// whose occupancy hangs on staying within 64 VGPRs, take VC_FIN_BATCH = 1 (they finalize at most a few hundred channels
+// per thread block anyway).
+template <int VC_FIN_BATCH = 1>
 __device__ __forceinline__ void vc_bn_fin_last(const VcBnFin& f, const float* stats, int C) {
     if (f.ticket == nullptr || stats == nullptr) return;
     if (!vc_last_workgroup(f.ticket)) return;
+    if (VC_FIN_BATCH == 1) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x)
+            vc_bn_finalize_channel<true>(stats, C, c, f.count, f.gamma, f.beta, f.running_mean, f.running_var, f.momentum,
+                                         f.eps, f.params, f.shift, f.shift_out);
+        return;
+    }
     const int step = (int)blockDim.x;
     for (int base = (int)threadIdx.x; base < C; base += step * VC_FIN_BATCH) {
         float s[VC_FIN_BATCH], q[VC_FIN_BATCH], g[VC_FIN_BATCH], b[VC_FIN_BATCH], rm[VC_FIN_BATCH], rv[VC_FIN_BATCH],
@@ -173,9 +182,15 @@ __device__ __forceinline__ void vc_bn_fin_last(const VcBnFin& f, const float* st
         }
     }
 }
+template <int VC_FIN_BATCH = 1>
 __device__ __forceinline__ void vc_bn_bwd_fin_last(const VcBnBwdFin& f, const float* sums, int C) {
     if (f.ticket == nullptr || sums == nullptr) return;
     if (!vc_last_workgroup(f.ticket)) return;
+    if (VC_FIN_BATCH == 1) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x)
+            vc_bn_bwd_finalize_channel<true>(sums, C, c, f.count, f.coef, f.dgamma, f.dbeta);
+        return;
+    }
     const int step = (int)blockDim.x;
     for (int base = (int)threadIdx.x; base < C; base += step * VC_FIN_BATCH) {
         float s[VC_FIN_BATCH], q[VC_FIN_BATCH], dg[VC_FIN_BATCH], db[VC_FIN_BATCH];

@@ -453,6 +453,167 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16x8* __restri
     }
 }
 
+// The reference's pool (kernel 3, stride 2, padding 1 on every axis) with BatchNorm + ReLU in front, tiled.
+// The thread-per-output kernel above reads every input element through ~3.4 overlapping windows (measured: 862 MB of
+// HBM traffic for a 411 MB tensor) and transforms it as often.  Here a workgroup owns one pooled row (n, ho) and walks
+// the T input planes once: the three input rows of a plane are loaded with coalesced 16-byte loads, transformed ONCE
+// (scale, shift, ReLU, bf16 rounding) and staged in LDS (double buffered; the next plane's loads are in flight while
+// this one is reduced).  Activations are >= 0, so their bf16 bits order like unsigned integers and value and tap go
+// into one key, (bits << 16) | (255 - tap): the maximum with the first tap winning a tie is an integer max.  The
+// in-plane 9-tap maximum of an odd plane 2c+1 serves window c (as kt = 2) and window c+1 (kt = 0): the tap byte is
+// 255 - 9 kt - j, so the second use is the same key plus 18 and each plane is reduced once.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+template <int MAXV, int NO>  // staged vectors / outputs per thread: 3 * rowv <= 256 * MAXV, Wo * groups <= 256 * NO
+__global__ __launch_bounds__(256) void maxpool_bn_tiled_kernel(const bf16x8* __restrict__ y, const float* __restrict__ params,
+                                                               bf16x8* __restrict__ out, uint8_t* __restrict__ idx,
+                                                               VcPoolGeom g) {
+    extern __shared__ __attribute__((aligned(16))) char pool_sm[];
+    const int groups = g.C >> 3;
+    const int rowv = g.W * groups;  // 16-byte vectors per input row
+    bf16x8* sZ = (bf16x8*)pool_sm;  // [2][3][rowv]
+    // consecutive pooled rows (which share an input row) on the same XCD: workgroups are dealt round-robin to the 8 XCDs
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    const int ho = bid % g.Ho, n = bid / g.Ho;
+    const int h0 = 2 * ho - 1;
+    const int cg = threadIdx.x % groups;  // 256 % groups == 0 (host check): fixed per thread in every loop below
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = params[2 * g.C + cg * 8 + k];
+        sh[k] = params[3 * g.C + cg * 8 + k];
+    }
+    // per-thread constants of the plane loop (no divisions or 64-bit multiplies inside it: the loop is VALU-bound)
+    bf16x8 ldA[MAXV], ldB[MAXV];  // two planes of loads in flight (one left HBM at 2.5 TB/s: too few bytes in flight per CU)
+    int src_off[MAXV];  // vector offset inside an input plane; -1: nothing to stage
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int i = threadIdx.x + u * 256;
+        const int b = i / rowv, r = i - b * rowv;
+        const int h = min(max(h0 + b, 0), g.H - 1);  // rows outside the image are never read back
+        src_off[u] = i < 3 * rowv ? h * rowv + r : -1;
+    }
+    const bf16x8* yplane = y + (long)n * g.T * g.H * rowv;
+    const long plane_stride = (long)g.H * rowv;
+    auto fetch = [&](bf16x8 (&ld)[MAXV]) {
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u)
+            if (src_off[u] >= 0) ld[u] = yplane[src_off[u]];
+        yplane += plane_stride;
+    };
+    auto stage = [&](int buf, const bf16x8 (&ld)[MAXV]) {
+        bf16x8* dst = sZ + buf * 3 * rowv + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u) {
+            if (src_off[u] >= 0) {
+                float f[8];
+                unpack8(ld[u], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float v = f[k] * sc[k] + sh[k];
+                    f[k] = v > 0.f ? v : 0.f;
+                }
+                dst[u * 256] = pack8(f);
+            }
+        }
+    };
+    int wo_[NO], tap_off[NO][3];  // pooled column; LDS vector offset of the window's three columns in a staged row
+    bool okw0[NO], okw2[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        wo_[o] = (threadIdx.x + o * 256) / groups;
+        const int w0 = 2 * wo_[o] - 1;
+        okw0[o] = w0 >= 0, okw2[o] = w0 + 2 < g.W;
+        tap_off[o][0] = max(w0, 0) * groups + cg;
+        tap_off[o][1] = min(w0 + 1, g.W - 1) * groups + cg;
+        tap_off[o][2] = min(w0 + 2, g.W - 1) * groups + cg;
+    }
+    const bool okh[3] = {h0 >= 0, true, h0 + 2 < g.H};
+    unsigned cur[NO][8], nxt[NO][8];  // the window being filled; the next one's kt = 0 plane
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cur[o][k] = nxt[o][k] = 0u;  // below every valid key (tap byte >= 1)
+    auto emit = [&](int to) {
+        if (to >= g.To) return;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const int wo = wo_[o];
+            if (wo >= g.Wo) continue;
+            float best[8];
+            uint64_t packed = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                best[k] = bf2f(__builtin_bit_cast(bf16, (unsigned short)(cur[o][k] >> 16)));
+                packed |= (uint64_t)(255u - (cur[o][k] & 0xffu)) << (8 * k);
+            }
+            const long e = ((((long)n * g.To + to) * g.Ho + ho) * g.Wo + wo) * groups + cg;
+            out[e] = pack8(best);
+            *(uint64_t*)(idx + e * 8) = packed;
+        }
+    };
+    auto plane = [&](int t, bf16x8 (&ld)[MAXV]) {
+        const int buf = t & 1;
+        stage(buf, ld);
+        __syncthreads();
+        if (t + 2 < g.T) fetch(ld);
+        const bf16x8* zb = sZ + buf * 3 * rowv;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            if (wo_[o] >= g.Wo) continue;  // threads beyond the row only stage
+            const bool okw[3] = {okw0[o], true, okw2[o]};
+            unsigned kp[8];  // in-plane maximum with tap byte 255 - j (kt = 0)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) kp[k] = 0u;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                if (!okh[b]) continue;  // uniform
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const u32x4 v = *(const u32x4*)&zb[b * rowv + tap_off[o][c]];
+                    const unsigned lb = 255u - (unsigned)(b * 3 + c);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        unsigned k0 = (v[m] << 16) | lb, k1 = (v[m] & 0xffff0000u) | lb;
+                        if (c != 1) {
+                            k0 = okw[c] ? k0 : 0u;
+                            k1 = okw[c] ? k1 : 0u;
+                        }
+                        kp[2 * m] = max(kp[2 * m], k0);
+                        kp[2 * m + 1] = max(kp[2 * m + 1], k1);
+                    }
+                }
+            }
+            if ((t & 1) == 0) {  // plane 2c: kt = 1 of window c
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cur[o][k] = max(cur[o][k], kp[k] - 9u);
+            } else {  // plane 2c+1: kt = 2 of window c; its kt = 0 use (window c+1) follows the emit below
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    cur[o][k] = max(cur[o][k], kp[k] - 18u);
+                    nxt[o][k] = kp[k];
+                }
+            }
+        }
+        if ((t & 1) == 1) {
+            emit(t >> 1);
+#pragma unroll
+            for (int o = 0; o < NO; ++o)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cur[o][k] = nxt[o][k];
+        } else if (t == g.T - 1) {
+            emit(t >> 1);
+        }
+    };
+    fetch(ldA);
+    if (g.T > 1) fetch(ldB);
+    for (int t = 0; t < g.T; t += 2) {
+        plane(t, ldA);
+        if (t + 1 < g.T) plane(t + 1, ldB);
+    }
+}
+
 // gradient of max pool w.r.t. its input, gather form: every input position looks at the
 // windows that contain it and takes the pooled gradient where it was the arg-max.
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16x8* __restrict__ dout, const uint8_t* __restrict__ idx,
@@ -677,6 +838,101 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pooled_kernel(const bf16x8* 
                 o[k] = kc.scale[k] * (gk - kc.c1[k] - xhat * kc.c2[k]);
             }
             drow[i] = pack8(o);
+        }
+    }
+}
+
+// The same pass for the reference's pool (kernel 3, stride 2, padding 1 on every axis), tiled: a workgroup owns the
+// input rows t in {2a+1, 2a+2} x h in {2b+1, 2b+2} of one clip and stages the four pooled rows (to in {a, a+1},
+// ho in {b, b+1}: gradient and arg-max bytes) that their windows live in into LDS with coalesced loads.  An odd
+// coordinate 2c+1 lies in windows c (as tap 2) and c+1 (tap 0), an even one 2c+2 in window c+1 only (tap 1), so the
+// candidate windows of a position are known from the parities: t and h are uniform over the workgroup and the w
+// loop runs over even then odd columns, which makes the candidate list wave-uniform -- 3.4 candidates per position
+// on average instead of eight predicated ones (the row-at-a-time kernel above spends its time in the 8 x 8 byte
+// compares: VALU-bound at 37 % of the HBM rate).  Sums are taken in (to, ho, wo) order like maxpool_bwd_kernel.
+__device__ __forceinline__ void pool_match8(float (&acc)[8], uint64_t pk, bf16x8 dv, int tap) {
+    const unsigned lo = (unsigned)pk, hi = (unsigned)(pk >> 32);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if ((int)((lo >> (8 * k)) & 0xffu) == tap) acc[k] += bf2f(dv[k]);
+        if ((int)((hi >> (8 * k)) & 0xffu) == tap) acc[4 + k] += bf2f(dv[4 + k]);
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_pooled_tiled_kernel(const bf16x8* __restrict__ y,
+                                                                        const bf16x8* __restrict__ dout,
+                                                                        const uint8_t* __restrict__ idx,
+                                                                        const float* __restrict__ params,
+                                                                        const float* __restrict__ coef,
+                                                                        bf16x8* __restrict__ dy, VcPoolGeom g, int nbt,
+                                                                        int nbh) {
+    extern __shared__ __attribute__((aligned(16))) char pool_sm[];
+    const int C = g.C, groups = C >> 3;
+    const int prow = g.Wo * groups;  // 16-byte vectors per pooled row
+    bf16x8* sD = (bf16x8*)pool_sm;                             // [2][2][prow]
+    uint64_t* sI = (uint64_t*)(pool_sm + (size_t)4 * prow * 16);  // [2][2][prow]
+    const int bh = blockIdx.x % nbh;
+    const int q = blockIdx.x / nbh;
+    const int bt = q % nbt, n = q / nbt;
+    const int a = bt - 1, b = bh - 1;
+    for (int s = 0; s < 4; ++s) {
+        const int to = a + (s >> 1), ho = b + (s & 1);
+        if (to < 0 || to >= g.To || ho < 0 || ho >= g.Ho) continue;  // uniform
+        const long base = (((long)n * g.To + to) * g.Ho + ho) * prow;
+        for (int i = threadIdx.x; i < prow; i += 256) {
+            sD[s * prow + i] = dout[base + i];
+            sI[s * prow + i] = *(const uint64_t*)(idx + (base + i) * 8);
+        }
+    }
+    const int cg = threadIdx.x % groups;  // 256 is a multiple of groups (host check)
+    BnBwdCoef kc;
+    load_bwd_coef(kc, params, coef, C, cg * 8);
+    __syncthreads();
+    const int per_row = g.W * groups;
+    const int half = 256 / groups;  // columns of one parity covered per trip
+    for (int r = 0; r < 4; ++r) {
+        const int t = 2 * a + 1 + (r >> 1), h = 2 * b + 1 + (r & 1);
+        if (t < 0 || t >= g.T || h < 0 || h >= g.H) continue;  // uniform
+        // candidate (slot, tap) pairs along t and h: odd -> windows {c (tap 2), c+1 (tap 0)}, even -> {c+1 (tap 1)}
+        const bool todd = (r >> 1) == 0, hodd = (r & 1) == 0;
+        const bool tv[2] = {todd && a >= 0 && a < g.To, a + 1 < g.To}, hv[2] = {hodd && b >= 0 && b < g.Ho, b + 1 < g.Ho};
+        const int tt[2] = {2, todd ? 0 : 1}, ht[2] = {2, hodd ? 0 : 1};  // slot i = window c + i
+        const long row = ((long)n * g.T + t) * g.H + h;
+        const bf16x8* yrow = y + row * per_row;
+        bf16x8* drow = dy + row * per_row;
+        for (int par = 0; par < 2; ++par) {
+            for (int j0 = 0; 2 * j0 + par < g.W; j0 += half) {
+                const int jw = j0 + threadIdx.x / groups;
+                const int w = 2 * jw + par;
+                if (w >= g.W) continue;
+                const bf16x8 yv = yrow[w * groups + cg];
+                float d[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] = 0.f;
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int ih = 0; ih < 2; ++ih) {
+                        if (!tv[it] || !hv[ih]) continue;  // uniform
+                        const int slot = (it * 2 + ih) * prow + cg;
+                        const int tap = (tt[it] * 3 + ht[ih]) * 3;
+                        if (par == 0) {  // w = 2 jw: window jw, tap 1
+                            if (jw < g.Wo) pool_match8(d, sI[slot + jw * groups], sD[slot + jw * groups], tap + 1);
+                        } else {  // w = 2 jw + 1: windows jw (tap 2) and jw + 1 (tap 0)
+                            if (jw < g.Wo) pool_match8(d, sI[slot + jw * groups], sD[slot + jw * groups], tap + 2);
+                            if (jw + 1 < g.Wo)
+                                pool_match8(d, sI[slot + (jw + 1) * groups], sD[slot + (jw + 1) * groups], tap);
+                        }
+                    }
+                float f[8], o[8];
+                unpack8(yv, f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float gk = (f[k] * kc.scale[k] + kc.shift[k]) > 0.f ? d[k] : 0.f;
+                    const float xhat = (f[k] - kc.mean[k]) * kc.invstd[k];
+                    o[k] = kc.scale[k] * (gk - kc.c1[k] - xhat * kc.c2[k]);
+                }
+                drow[w * groups + cg] = pack8(o);
+            }
         }
     }
 }
@@ -1162,6 +1418,28 @@ int vc_ew_add(const void* a, const void* b, void* out, long n, hipStream_t s) {
 }
 int vc_ew_maxpool_fwd(const void* y, const float* params, void* out, uint8_t* idx, const VcPoolGeom& g, hipStream_t s) {
     const long total = (long)g.N * g.To * g.Ho * g.Wo * (g.C / 8);
+    const int groups = g.C / 8;
+    const bool ref_pool = g.kt == 3 && g.kh == 3 && g.kw == 3 && g.st == 2 && g.sh == 2 && g.sw == 2 && g.pt == 1 &&
+                          g.ph == 1 && g.pw == 1;
+    if (params && ref_pool && getenv("VC_POOL_FWD_GATHER") == nullptr && groups <= 256 && 256 % groups == 0 &&
+        g.W * groups <= 1024 && g.Wo * groups <= 512) {
+        const size_t lds = (size_t)2 * 3 * g.W * groups * 16;
+        const bool small = 3 * g.W * groups <= 256 * 6 && g.Wo * groups <= 256;
+        if (lds > 64 * 1024) {
+            static VcPerDeviceOnce once;
+            once.run([&] {
+                (void)hipFuncSetAttribute((const void*)maxpool_bn_tiled_kernel<12, 2>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * 1024 * 16);
+            });
+        }
+        if (small)
+            VC_LAUNCH((maxpool_bn_tiled_kernel<6, 1>), dim3((unsigned)(g.N * g.Ho)), dim3(256), lds, s, (const bf16x8*)y,
+                      params, (bf16x8*)out, idx, g);
+        else
+            VC_LAUNCH((maxpool_bn_tiled_kernel<12, 2>), dim3((unsigned)(g.N * g.Ho)), dim3(256), lds, s, (const bf16x8*)y,
+                      params, (bf16x8*)out, idx, g);
+        return VC_CHECK_LAUNCH();
+    }
     if (params)
         VC_LAUNCH((maxpool_fwd_kernel<true>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16x8*)y, params,
                            (bf16x8*)out, idx, g);
@@ -1274,6 +1552,17 @@ int vc_ew_bn_bwd_reduce_pooled(const void* y, const void* dout, const uint8_t* i
 int vc_ew_bn_bwd_apply_pooled(const void* y, const void* dout, const uint8_t* idx, const float* params, const float* coef,
                               void* dy, const VcPoolGeom& g, hipStream_t s) {
     const int nrows = g.N * g.T * g.H;
+    const int groups = g.C / 8;
+    const size_t lds = (size_t)4 * g.Wo * groups * 24;
+    const bool ref_pool = g.kt == 3 && g.kh == 3 && g.kw == 3 && g.st == 2 && g.sh == 2 && g.sw == 2 && g.pt == 1 &&
+                          g.ph == 1 && g.pw == 1;
+    const bool rowwise = getenv("VC_POOL_BWD_ROWWISE") != nullptr;  // the row-at-a-time kernel (A/B runs, tests)
+    if (ref_pool && !rowwise && groups <= 256 && 256 % groups == 0 && lds <= 64 * 1024) {
+        const int nbt = (g.T >> 1) + 1, nbh = (g.H >> 1) + 1;
+        VC_LAUNCH(bn_bwd_apply_pooled_tiled_kernel, dim3((unsigned)(g.N * nbt * nbh)), dim3(256), lds, s, (const bf16x8*)y,
+                  (const bf16x8*)dout, idx, params, coef, (bf16x8*)dy, g, nbt, nbh);
+        return VC_CHECK_LAUNCH();
+    }
     VC_LAUNCH(bn_bwd_apply_pooled_kernel, dim3(nrows < 4096 ? nrows : 4096), dim3(256), 0, s, (const bf16x8*)y,
               (const bf16x8*)dout, idx, params, coef, (bf16x8*)dy, g);
     return VC_CHECK_LAUNCH();

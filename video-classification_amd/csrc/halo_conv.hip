@@ -584,7 +584,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     }
     VC_STAMP(7);
-    vc_bn_fin_last(p.fin, p.stats, p.Cn);
+    vc_bn_fin_last<4>(p.fin, p.stats, p.Cn);
 }
 
 // LDS bytes of a workgroup: ring + zero row + the larger of the image and the epilogue staging area

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
             atomicAdd(srep + mom * p.Cn + co0 + c, v);
         }
     }
-    if (p.partial == nullptr) vc_bn_fin_last(p.fin, p.stats, p.Cn);
+    if (p.partial == nullptr) vc_bn_fin_last<4>(p.fin, p.stats, p.Cn);
 }
 
 template <int BCO, int BM, int MODE>
