@@ -173,8 +173,13 @@ int vc_bn_eval_params(int32_t C, const float* gamma, const float* beta, const fl
                       const float* running_var, float eps, float* params, void* stream);
 int vc_bn_apply(const void* y, const float* params, const void* residual /* nullable */, void* out,
                 int64_t elems, int32_t C, int32_t relu, void* stream);
+/* vc_bn_apply with relu = 1 that also writes the ReLU mask of its output, one bit per element (relu_bits: elems / 8
+ * bytes; bit k of byte i = out[8 i + k] > 0): the backward of `out += residual; relu` (backbone.py:59-61,100-102)
+ * then reads 1 bit per element instead of the 16-bit activation (mask mode 3 below). */
+int vc_bn_apply_mask(const void* y, const float* params, const void* residual /* nullable */, void* out,
+                     uint8_t* relu_bits, int64_t elems, int32_t C, void* stream);
 /* mask: 0 none; 1 gradient passes where aux (saved post-activation output) > 0;
- *       2 where y*scale+shift > 0 (recomputed) */
+ *       2 where y*scale+shift > 0 (recomputed); 3 where the bit of aux = vc_bn_apply_mask's relu_bits is set */
 int vc_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums,
                      int64_t rows, int32_t C, int32_t mask, void* stream);
 int vc_bn_bwd_finalize(const float* sums, int32_t C, float count, float* coef /* [2][C] */,

@@ -246,6 +246,19 @@ def test_batchnorm_fwd_bwd(C, shape, mode):
         assert int(ticket.abs().sum().item()) == 0
         assert rel_l2(dy3.float(), dy.float()) <= 1e-3
         assert torch.allclose(dg3, dgamma, rtol=1e-4, atol=1e-5) and torch.allclose(db3, dbeta, rtol=1e-4, atol=1e-5)
+    if mode != "plain":
+        # the ReLU mask as bits (vc_bn_apply_mask, mask mode 3): same output, bit k of byte i = out[8 i + k] > 0, and a
+        # backward identical to the one that reads the activation
+        bits = torch.empty(yd.numel() // 8, dtype=torch.uint8, device="cuda")
+        zb = ops.bn_apply(yd, params, C, residual=resd, relu=True, relu_bits=bits)
+        assert torch.equal(zb, z)
+        want = ((z.reshape(-1, 8) > 0).to(torch.int32) << torch.arange(8, device="cuda", dtype=torch.int32)).sum(1)
+        assert torch.equal(bits.to(torch.int32), want)
+        dg4, db4 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dy4, gm4 = ops.bn_bwd(yd, to_nthwc_dev(dz), params, C, dg4, db4, mask=3, aux=bits, want_g=True)
+        torch.cuda.synchronize()
+        assert torch.equal(dy4, dy) and torch.equal(gm4, gm)
+        assert torch.allclose(dg4, dgamma, rtol=1e-5, atol=1e-6) and torch.allclose(db4, dbeta, rtol=1e-5, atol=1e-6)
     if mode == "relu":
         # recomputed mask (y*scale+shift > 0) must agree with the saved-output mask
         dg2 = torch.zeros(C, device="cuda")

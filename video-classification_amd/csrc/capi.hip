@@ -307,7 +307,7 @@ static int conv3d_fwd_impl(const vc_conv3d_desc* d, const void* x, const void* w
         if (rc) return rc;
         rc = vc_ew_splitk_finalize(p.partial, splits, p.partial_stride, y, 0, bn_stats, p.M, d->Co, fin, S(stream));
         if (rc || ep_params == nullptr) return rc;
-        return vc_ew_bn_apply(y, ep_params, ep_res, y, (long)out_e, d->Co, ep_relu, S(stream));  // in place
+        return vc_ew_bn_apply(y, ep_params, ep_res, y, (long)out_e, d->Co, ep_relu, nullptr, S(stream));  // in place
     }
     if (fin != nullptr && bn_stats != nullptr) p.fin = *fin, p.stat_shift = fin->shift;
     p.ep_params = ep_params, p.ep_relu = ep_relu, p.ep_res = (const bf16*)ep_res;
@@ -430,7 +430,7 @@ static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const 
         rc = vc_ew_splitk_finalize(p.partial, plan.splits, p.partial_stride, out, accumulate, stats,
                                    (long)(out_e / p.Cn), p.Cn, stats ? fin : nullptr, S(stream));
         if (rc || ep_params == nullptr) return rc;
-        return vc_ew_bn_apply(out, ep_params, ep_res, out, (long)out_e, p.Cn, ep_relu, S(stream));  // in place
+        return vc_ew_bn_apply(out, ep_params, ep_res, out, (long)out_e, p.Cn, ep_relu, nullptr, S(stream));  // in place
     }
     p.ep_params = ep_params, p.ep_relu = ep_relu, p.ep_res = (const bf16*)ep_res;
     // The halo kernel runs several rounds of one workgroup per CU: a ticket round trip at the end of every workgroup
@@ -906,13 +906,19 @@ int vc_bn_apply(const void* y, const float* params, const void* residual, void* 
                 int32_t relu, void* stream) {
     VC_REQUIRE(y && params && out && elems > 0, "bn_apply: bad arguments");
     VC_REQUIRE(C % 8 == 0 && elems % C == 0, "bn_apply: C=%d must divide elems and be a multiple of 8", C);
-    return vc_ew_bn_apply(y, params, residual, out, elems, C, relu, S(stream));
+    return vc_ew_bn_apply(y, params, residual, out, elems, C, relu, nullptr, S(stream));
+}
+int vc_bn_apply_mask(const void* y, const float* params, const void* residual, void* out, uint8_t* relu_bits, int64_t elems,
+                     int32_t C, void* stream) {
+    VC_REQUIRE(y && params && out && relu_bits && elems > 0, "bn_apply_mask: bad arguments");
+    VC_REQUIRE(C % 8 == 0 && elems % C == 0, "bn_apply_mask: C=%d must divide elems and be a multiple of 8", C);
+    return vc_ew_bn_apply(y, params, residual, out, elems, C, 1, relu_bits, S(stream));
 }
 int vc_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums, int64_t rows,
                      int32_t C, int32_t mask, void* stream) {
     VC_REQUIRE(y && dz && params && sums && rows > 0, "bn_bwd_reduce: bad arguments");
     VC_REQUIRE(pow2_channels(C), "bn: C=%d must be a power of two in [64, 2048]", C);
-    VC_REQUIRE(mask >= 0 && mask <= 2 && (mask != 1 || aux), "bn_bwd_reduce: bad mask mode");
+    VC_REQUIRE(mask >= 0 && mask <= 3 && ((mask != 1 && mask != 3) || aux), "bn_bwd_reduce: bad mask mode");
     return vc_ew_bn_bwd_reduce(y, dz, aux, params, sums, rows, C, mask, nullptr, S(stream));
 }
 int vc_bn_bwd_reduce_fin(const void* y, const void* dz, const void* aux, const float* params, float* sums, int64_t rows,
@@ -920,7 +926,7 @@ int vc_bn_bwd_reduce_fin(const void* y, const void* dz, const void* aux, const f
                          void* stream) {
     VC_REQUIRE(y && dz && params && sums && rows > 0, "bn_bwd_reduce_fin: bad arguments");
     VC_REQUIRE(pow2_channels(C), "bn: C=%d must be a power of two in [64, 2048]", C);
-    VC_REQUIRE(mask >= 0 && mask <= 2 && (mask != 1 || aux), "bn_bwd_reduce_fin: bad mask mode");
+    VC_REQUIRE(mask >= 0 && mask <= 3 && ((mask != 1 && mask != 3) || aux), "bn_bwd_reduce_fin: bad mask mode");
     VC_REQUIRE(ticket && coef, "bn_bwd_reduce_fin: ticket and coef are required");
     const VcBnBwdFin f = {ticket, coef, dgamma, dbeta, (float)rows};
     return vc_ew_bn_bwd_reduce(y, dz, aux, params, sums, rows, C, mask, &f, S(stream));
@@ -934,7 +940,7 @@ int vc_bn_bwd_apply(const void* y, const void* dz, const void* aux, const float*
                     void* g_out, int64_t elems, int32_t C, int32_t mask, void* stream) {
     VC_REQUIRE(y && dz && params && coef && dy && elems > 0, "bn_bwd_apply: bad arguments");
     VC_REQUIRE(C % 8 == 0 && elems % C == 0, "bn_bwd_apply: C=%d must divide elems and be a multiple of 8", C);
-    VC_REQUIRE(mask >= 0 && mask <= 2 && (mask != 1 || aux), "bn_bwd_apply: bad mask mode");
+    VC_REQUIRE(mask >= 0 && mask <= 3 && ((mask != 1 && mask != 3) || aux), "bn_bwd_apply: bad mask mode");
     return vc_ew_bn_bwd_apply(y, dz, aux, params, coef, dy, g_out, elems, C, mask, S(stream));
 }
 int vc_add(const void* a, const void* b, void* out, int64_t elems, void* stream) {

@@ -19,8 +19,9 @@ int vc_ew_lstm_pointwise_bwd(const float* dh, const float* dc_next, const float*
                              float* dc_prev, float* db_ih, float* db_hh, int N, int H, hipStream_t s);
 int vc_ew_bn_eval_params(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
                          float* params, hipStream_t s);
+// bits (nullable; needs relu): one byte per 8 channels, bit k = (out[k] > 0)
 int vc_ew_bn_apply(const void* y, const float* params, const void* res, void* out, long n, int C, int relu,
-                   hipStream_t s);
+                   uint8_t* bits, hipStream_t s);
 // shift_out (nullable): the sums are taken relative to row 0 of y, which is written there for the finalize
 int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, float* shift_out, hipStream_t s);
 int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const float* params, float* sums, long rows,

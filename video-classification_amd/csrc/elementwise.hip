@@ -44,11 +44,15 @@ __global__ void bn_eval_params_kernel(int C, const float* gamma, const float* be
     params[3 * C + c] = beta[c] - running_mean[c] * scale;
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
 // ------------------------------------------------------------------ BN apply (+res)(+relu)
-template <bool RES, bool RELU>
+// BITS: also write one byte per 8 channels, bit k = (out[k] > 0) -- the ReLU mask of a residual block's output for
+// the backward passes (MASK 3 below), which then read 1 bit per element instead of the 16-bit activation.
+template <bool RES, bool RELU, bool BITS = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16x8* __restrict__ y, const float* __restrict__ params,
                                                        const bf16x8* __restrict__ res, bf16x8* __restrict__ out,
-                                                       long n8, int C) {
+                                                       long n8, int C, uint8_t* __restrict__ bits = nullptr) {
     const float* scale = params + 2 * C;
     const float* shift = params + 3 * C;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -75,7 +79,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16x8* __restrict_
             if (RELU) v = v > 0.f ? v : 0.f;
             f[k] = v;
         }
-        out[i] = pack8(f);
+        const bf16x8 o = pack8(f);
+        out[i] = o;
+        if (BITS) {  // from the rounded values: the mask is exactly (out > 0)
+            const u32x4 w = __builtin_bit_cast(u32x4, o);
+            unsigned b = 0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                b |= ((w[m] & 0xffffu) != 0u ? 1u << (2 * m) : 0u) | ((w[m] >> 16) != 0u ? 2u << (2 * m) : 0u);
+            bits[i] = (uint8_t)b;
+        }
     }
 }
 
@@ -83,7 +96,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16x8* __restrict_
 // MODE 0: sum y, sum y^2 (standalone BN statistics)
 // MODE 1: BN backward sums: sum g, sum g*xhat with g = dz * mask
 //   MASK 0 none, 1 mask = (aux > 0) with aux the saved post-activation output,
-//        2 mask = (y*scale+shift > 0) recomputed
+//        2 mask = (y*scale+shift > 0) recomputed,
+//        3 mask = bit k of byte aux[i] (written by bn_apply_kernel<.., BITS>: the same mask as 1 at 1/16 of the bytes)
 // A block owns a 64-channel slice (8 lanes x 16 bytes = one 128-byte piece of every row it visits) and every RS-th
 // group of 32 rows; it reduces its partial sums through LDS and adds them to one of VC_STAT_REPLICAS copies of
 // sums[2][C].  The number of float atomics of a launch is RS x 2C whatever the channel split, so wide layers get
@@ -141,11 +155,13 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restri
             float d[8], m[8];
             unpack8(dz[i], d);
             if (MASK == 1) unpack8(aux[i], m);
+            const unsigned mb = MASK == 3 ? ((const uint8_t*)aux)[i] : 0u;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float gk = d[k];
                 if (MASK == 1) gk = m[k] > 0.f ? gk : 0.f;
                 if (MASK == 2) gk = (f[k] * scale[k] + shift[k]) > 0.f ? gk : 0.f;
+                if (MASK == 3) gk = ((mb >> k) & 1u) ? gk : 0.f;
                 a0[k] += gk;
                 a1[k] += gk * (f[k] - mean[k]) * invstd[k];
             }
@@ -322,11 +338,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16x8* __restr
         unpack8(y[i], f);
         unpack8(dz[i], d);
         if (MASK == 1) unpack8(aux[i], m);
+        const unsigned mb = MASK == 3 ? ((const uint8_t*)aux)[i] : 0u;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float gk = d[k];
             if (MASK == 1) gk = m[k] > 0.f ? gk : 0.f;
             if (MASK == 2) gk = (f[k] * kc.scale[k] + kc.shift[k]) > 0.f ? gk : 0.f;
+            if (MASK == 3) gk = ((mb >> k) & 1u) ? gk : 0.f;
             const float xhat = (f[k] - kc.mean[k]) * kc.invstd[k];
             o[k] = kc.scale[k] * (gk - kc.c1[k] - xhat * kc.c2[k]);
             d[k] = gk;
@@ -462,7 +480,6 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16x8* __restri
 // into one key, (bits << 16) | (255 - tap): the maximum with the first tap winning a tie is an integer max.  The
 // in-plane 9-tap maximum of an odd plane 2c+1 serves window c (as kt = 2) and window c+1 (kt = 0): the tap byte is
 // 255 - 9 kt - j, so the second use is the same key plus 18 and each plane is reduced once.
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 template <int MAXV, int NO>  // staged vectors / outputs per thread: 3 * rowv <= 256 * MAXV, Wo * groups <= 256 * NO
 __global__ __launch_bounds__(256) void maxpool_bn_tiled_kernel(const bf16x8* __restrict__ y, const float* __restrict__ params,
                                                                bf16x8* __restrict__ out, uint8_t* __restrict__ idx,
@@ -1307,20 +1324,24 @@ int vc_ew_bn_eval_params(int C, const float* gamma, const float* beta, const flo
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_apply(const void* y, const float* params, const void* res, void* out, long n, int C, int relu,
-                   hipStream_t s) {
+                   uint8_t* bits, hipStream_t s) {
     const long n8 = n / 8;
     const int g = grid_for(n8);
     const bf16x8* yy = (const bf16x8*)y;
     const bf16x8* rr = (const bf16x8*)res;
     bf16x8* oo = (bf16x8*)out;
-    if (res && relu)
-        VC_LAUNCH((bn_apply_kernel<true, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+    if (bits && res)
+        VC_LAUNCH((bn_apply_kernel<true, true, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C, bits);
+    else if (bits)
+        VC_LAUNCH((bn_apply_kernel<false, true, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C, bits);
+    else if (res && relu)
+        VC_LAUNCH((bn_apply_kernel<true, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C, (uint8_t*)nullptr);
     else if (res)
-        VC_LAUNCH((bn_apply_kernel<true, false>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+        VC_LAUNCH((bn_apply_kernel<true, false>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C, (uint8_t*)nullptr);
     else if (relu)
-        VC_LAUNCH((bn_apply_kernel<false, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+        VC_LAUNCH((bn_apply_kernel<false, true>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C, (uint8_t*)nullptr);
     else
-        VC_LAUNCH((bn_apply_kernel<false, false>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C);
+        VC_LAUNCH((bn_apply_kernel<false, false>), dim3(g), dim3(256), 0, s, yy, params, rr, oo, n8, C, (uint8_t*)nullptr);
     return VC_CHECK_LAUNCH();
 }
 
@@ -1354,6 +1375,9 @@ int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const fl
                   VcBnFin{}, bf, (float*)nullptr);
     else if (mask == 1)
         VC_LAUNCH((chan_reduce_kernel<1, 1>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
+                  VcBnFin{}, bf, (float*)nullptr);
+    else if (mask == 3)
+        VC_LAUNCH((chan_reduce_kernel<1, 3>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
                   VcBnFin{}, bf, (float*)nullptr);
     else
         VC_LAUNCH((chan_reduce_kernel<1, 2>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
@@ -1401,10 +1425,12 @@ int vc_ew_bn_bwd_apply(const void* y, const void* dz, const void* aux, const flo
     if (gout) {
         if (mask == 0) VC_BWD_APPLY(0, true);
         else if (mask == 1) VC_BWD_APPLY(1, true);
+        else if (mask == 3) VC_BWD_APPLY(3, true);
         else VC_BWD_APPLY(2, true);
     } else {
         if (mask == 0) VC_BWD_APPLY(0, false);
         else if (mask == 1) VC_BWD_APPLY(1, false);
+        else if (mask == 3) VC_BWD_APPLY(3, false);
         else VC_BWD_APPLY(2, false);
     }
 #undef VC_BWD_APPLY

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "vc_bn_finalize": [_P, _I, _F, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P],
     "vc_bn_eval_params": [_I, _P, _P, _P, _P, _F, _P, _P],
     "vc_bn_apply": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "vc_bn_apply_mask": [_P, _P, _P, _P, _P, _L, _I, _P],
     "vc_bn_bwd_reduce": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "vc_bn_bwd_reduce_fin": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P],
     "vc_bn_bwd_finalize": [_P, _I, _F, _P, _P, _P, _P],

@@ -22,6 +22,7 @@ F32 = torch.float32
 FUSED_EVAL_ACT = os.environ.get("VC_NO_EVAL_ACT") is None  # inference: BatchNorm + ReLU in the conv epilogue
 FUSED_BN_FIN = os.environ.get("VC_NO_BN_FIN") is None  # BatchNorm finalize done by the last workgroup of the producer
 SIDE_WGRAD = os.environ.get("VC_WGRAD_SIDE_STREAM", "1") != "0"  # weight gradients on a side stream (engine._wgrad)
+RELU_BITS = os.environ.get("VC_NO_RELU_BITS") is None  # residual blocks save their ReLU mask as bits (VC_NO_RELU_BITS=1: read the activation instead)
 FIRST_STATS = os.environ.get("VC_FIRST_STATS") is not None  # stand-alone row-0-shifted statistics on a layer's first step
 
 
@@ -448,8 +449,10 @@ class R3DEngine:
                     else:
                         dd = yd = prmd = None
                         r = xin
-                    out = ops.bn_apply(y, prm, cb.Co, residual=r, relu=True)
-                    recs.append((d, h, y, prm, out))
+                    # the block output's ReLU mask as bits for the backward (it reads 1 bit, not 16, per element)
+                    bits = torch.empty(y.numel() // 8, dtype=torch.uint8, device=y.device) if save and RELU_BITS else None
+                    out = ops.bn_apply(y, prm, cb.Co, residual=r, relu=True, relu_bits=bits)
+                    recs.append((d, h, y, prm, out if bits is None else bits))
                     dsrec = (dd, yd, prmd)
                     self._t(cb.name, x=h, y=y, prm=prm, out=out, res=r, relu=True)
             if save:
@@ -477,9 +480,10 @@ class R3DEngine:
         for (cbs, ds), (xin, recs, dsrec) in zip(reversed(self.blocks), reversed(saved["blocks"])):
             # last conv of the block: BN + residual + ReLU
             cb = cbs[-1]
-            d, h, y, prm, out = recs[-1]
-            dy, gres = ops.bn_bwd(y, g, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias), mask=1,
-                                  aux=out, want_g=True, sums=sums_pool.take(cb.Co), ticket=self._bticket(cb))
+            d, h, y, prm, out = recs[-1]  # `out`: the block output, or its ReLU mask as bits
+            dy, gres = ops.bn_bwd(y, g, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias),
+                                  mask=3 if out.dtype == torch.uint8 else 1, aux=out, want_g=True,
+                                  sums=sums_pool.take(cb.Co), ticket=self._bticket(cb))
             self._ready(cb.bn.weight, cb.bn.bias)
             self._wgrad(d, h, dy, cb.conv)
             _, wd = cb.weights()

@@ -367,13 +367,22 @@ def bn_eval_params(gamma, beta, running_mean, running_var, eps, params=None):
     return params
 
 
-def bn_apply(y, params, C, residual=None, relu=True, out=None):
+def bn_apply(y, params, C, residual=None, relu=True, out=None, relu_bits=None):
+    """relu_bits (uint8, y.numel() / 8 bytes; needs relu): also receives the ReLU mask of `out`, one bit per element --
+    what bn_bwd(mask=3, aux=relu_bits) reads in place of the activation."""
     _chk(y, BF16, name="y")
     _chk(params, F32, 4 * C, "bn params")
     _chk(residual, BF16, y.numel(), "residual")
     if out is None:
         out = torch.empty_like(y)
     _chk(out, BF16, y.numel(), "out")
+    if relu_bits is not None:
+        if not relu:
+            raise capi.Vc3dError("bn_apply: relu_bits needs relu=True")
+        _chk(relu_bits, torch.uint8, y.numel() // 8, "relu_bits")
+        check(lib.vc_bn_apply_mask(ptr(y), ptr(params), ptr(residual), ptr(out), ptr(relu_bits), y.numel(), C,
+                                   cur_stream()), "vc_bn_apply_mask")
+        return out
     check(lib.vc_bn_apply(ptr(y), ptr(params), ptr(residual), ptr(out), y.numel(), C, 1 if relu else 0,
                           cur_stream()), "vc_bn_apply")
     return out
@@ -386,7 +395,10 @@ def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=Fal
     n = y.numel()
     _chk(y, BF16, name="y")
     _chk(dz, BF16, n, "dz")
-    _chk(aux, BF16, n, "aux")
+    if mask == 3:
+        _chk(aux, torch.uint8, n // 8, "aux (relu bits)")
+    else:
+        _chk(aux, BF16, n, "aux")
     _chk(params, F32, 4 * C, "bn params")
     _chk(gamma_grad, F32, C, "dgamma")
     _chk(beta_grad, F32, C, "dbeta")
