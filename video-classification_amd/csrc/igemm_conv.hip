@@ -146,6 +146,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
         unsigned* sRowMask = (unsigned*)(sRowBase + BM);
         int* sOutOff = (int*)(sRowMask + BM);
         int my_ooff = -1;  // out offset of row tid (BM <= 256), put back into LDS for the staged store
+        int ooff[4];
+        if (MODE == 0 && p.pointwise) {
+            // 1x1x1, unit stride, dense output: no gather, no bounds -- the row table (and its two barriers) is arithmetic
+            if (tid < BM) my_ooff = m0 + tid < M ? out_base + (m0 + tid) * p.Cn : -1;
+#pragma unroll
+            for (int i = 0; i < Cfg::NX; ++i) {
+                const int m = m0 + i * 32 + lrow;
+                rb[i] = (m < M ? m : 0) * p.Cs + lslot * 8;
+                rm[i] = m < M ? 1u : 0u;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int m = m0 + wm * 64 + b * 16 + l15;
+                ooff[b] = m < M ? out_base + m * p.Cn : -1;
+            }
+        } else {
         for (int r = tid; r < BM; r += 256) {
             const int m = m0 + r;
             int base = 0, ooff = -1;
@@ -183,10 +199,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
             rb[i] = sRowBase[i * 32 + lrow] + (MODE == 0 ? lslot * 8 : 0);
             rm[i] = sRowMask[i * 32 + lrow];
         }
-        int ooff[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) ooff[b] = sOutOff[wm * 64 + b * 16 + l15];
         __syncthreads();  // the row table has been consumed; buffer 0 may be overwritten
+        }
 
         f32x4 acc[4][4];
 #pragma unroll
@@ -419,6 +435,11 @@ int vc_launch_igemm(const VcIgemmParams& p, int mode, hipStream_t stream) {
         return -2;
     }
     if (mode == 1) return launch_igemm<64, 256, 1>(p, stream);
-    if (p.Cn % 128 == 0 && p.Cn >= 128) return launch_igemm<128, 128, 0>(p, stream);
-    return launch_igemm<64, 256, 0>(p, stream);
+    VcIgemmParams q = p;
+    q.pointwise = p.ncls <= 1 && p.ntaps == 1 && p.taps[0].ot == 0 && p.taps[0].oh == 0 && p.taps[0].ow == 0 &&
+                  p.taps[0].src_off == 0 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.Ts == p.Ta && p.Hs == p.Ha &&
+                  p.Ws == p.Wa && p.out_w == p.Cn && p.out_h == p.Wa * p.Cn && p.out_t == p.Ha * p.Wa * p.Cn &&
+                  p.out_n == p.Ta * p.Ha * p.Wa * p.Cn && getenv("VC_NO_POINTWISE") == nullptr;
+    if (p.Cn % 128 == 0 && p.Cn >= 128) return launch_igemm<128, 128, 0>(q, stream);
+    return launch_igemm<64, 256, 0>(q, stream);
 }

@@ -20,6 +20,7 @@ struct VcIgemmParams {
     int ntaps, Kw, Cn;
     int out_n, out_t, out_h, out_w, out_base;
     int accumulate;
+    int pointwise;  // set by vc_launch_igemm: one centred tap, unit stride, dense output -- row m is row m of src and out
     // split-K: blockIdx.z handles chunks [z*cps, (z+1)*cps); partial sums go to fp32 slabs
     // partial[z][same element offsets as out]; a finalize kernel sums, rounds and takes BN statistics
     int splits, cps;
