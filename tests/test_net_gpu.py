@@ -267,8 +267,8 @@ def test_production_order_matches_the_traced_order(monkeypatch):
     gradients on the main stream and takes the stem's BatchNorm backward through a materialised pool-input gradient.
     Here the production order (weight gradients on the side stream behind events, the pooled shortcut, ReLU masks as
     bits) runs the same step: every gradient of the residual stages must agree with the traced run to within the
-    rerun noise of this configuration, the stem's (whose pool-input gradient stays fp32 in the shortcut instead of
-    being rounded to bf16) to 5e-3.  A missing event between the two streams shows as an O(1) deviation."""
+    rerun noise of this configuration (4x), the stem's (whose pool-input gradient stays fp32 in the shortcut instead of
+    being rounded to bf16) to that or 5e-3.  A missing event between the two streams shows as an O(1) deviation."""
     if not torch.cuda.is_available():
         pytest.skip("needs the GPU")
     from oracle.r3d_torch import synthetic_batch
@@ -297,5 +297,5 @@ def test_production_order_matches_the_traced_order(monkeypatch):
         stem = n.startswith("backbone.conv1") or n.startswith("backbone.bn1")
         d = rel_l2(g_t[n], g_a[n])
         worst["stem" if stem else "stages"] = max(worst.get("stem" if stem else "stages", 0.0), d)
-        assert d <= (5e-3 if stem else max(4 * noise, 1e-5)), (n, d, noise)
+        assert d <= max(4 * noise, 5e-3 if stem else 1e-5), (n, d, noise)
     print("traced vs production: %s" % {k: "%.2e" % v for k, v in worst.items()})

@@ -695,3 +695,48 @@ def test_batchnorm_variance_survives_a_large_mean():
           % (abs(m64) / v64 ** 0.5, errs[0], errs[1]))
     assert float((shift.double() - m64).abs().max()) <= 1e-5 * abs(m64)
     assert errs[1][0] <= 1e-6 and errs[1][1] <= 1e-3
+
+
+@pytest.mark.parametrize("geom", [(64, 256, 8, 28, 28, 64), (64, 64, 8, 28, 28, 256), (2, 2048, 1, 2, 2, 512),
+                                  (3, 256, 2, 7, 7, 1024), (5, 128, 4, 14, 14, 512), (1, 64, 1, 3, 5, 64)])
+def test_pointwise_kernel_matches_general_kernel(geom):
+    """pw_conv.hip (the dense 1x1x1 GEMM: three workgroups per CU, BatchNorm finalize per co block) against the general
+    implicit-GEMM kernel on the same inputs (VC_NO_PW_KERNEL is read per call): bit-equal outputs in forward, dgrad and
+    accumulating dgrad -- same tile, same summation order -- and BatchNorm parameters / running statistics equal to the
+    order of the float atomics.  The first two geometries give a workgroup several tiles of several K chunks."""
+    _need_gpu()
+    from vc3d import ops
+    N, Ci, T, H, W, Co = geom
+    d = ops.conv_desc(N, Ci, T, H, W, Co, 1, 1, 0)
+    M = N * T * H * W
+    g = torch.Generator().manual_seed(Ci + Co)
+    x = torch.randn(N, T, H, W, Ci, generator=g).to(torch.bfloat16).cuda()
+    dy = torch.randn(N, T, H, W, Co, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(Co, Ci, 1, 1, 1, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last_3d)
+    wf, wd = ops.pack_weight(w)
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).cuda(), torch.randn(Co, generator=g).cuda()
+    base = torch.randn(N, T, H, W, Ci, generator=g).to(torch.bfloat16).cuda()
+
+    def run():
+        stats = ops.new_stats(Co, x.device)
+        rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        ticket = torch.zeros(64, dtype=torch.int32, device="cuda")
+        fin, params = ops.bn_fin(ticket, M, gamma, beta, rm, rv, 0.1, 1e-5)
+        y = ops.conv3d_fwd(d, x, wf, stats=stats, fin=fin)
+        dx = ops.conv3d_dgrad(d, dy, wd)
+        acc = base.clone()
+        ops.conv3d_dgrad(d, dy, wd, out=acc, accumulate=True)
+        torch.cuda.synchronize()
+        assert int(ticket.abs().sum()) == 0
+        return y, dx, acc, params.clone(), rm, rv
+
+    os.environ["VC_NO_PW_KERNEL"] = "1"
+    try:
+        ref = run()
+    finally:
+        del os.environ["VC_NO_PW_KERNEL"]
+    got = run()
+    for a, b in zip(got[:3], ref[:3]):
+        assert torch.equal(a, b)
+    for a, b in zip(got[3:], ref[3:]):
+        assert rel_l2(a.cpu(), b.cpu()) <= 1e-5

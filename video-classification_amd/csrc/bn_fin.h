@@ -145,6 +145,7 @@ __device__ __forceinline__ void vc_bn_fin_last(const VcBnFin& f, const float* st
         return;
     }
     const int step = (int)blockDim.x;
+#pragma clang loop unroll(disable)  // unrolled, this tail sets the whole kernel's register allocation (and occupancy)
     for (int base = (int)threadIdx.x; base < C; base += step * VC_FIN_BATCH) {
         float s[VC_FIN_BATCH], q[VC_FIN_BATCH], g[VC_FIN_BATCH], b[VC_FIN_BATCH], rm[VC_FIN_BATCH], rv[VC_FIN_BATCH],
             sh[VC_FIN_BATCH];
@@ -192,6 +193,7 @@ __device__ __forceinline__ void vc_bn_bwd_fin_last(const VcBnBwdFin& f, const fl
         return;
     }
     const int step = (int)blockDim.x;
+#pragma clang loop unroll(disable)  // unrolled, this tail sets the whole kernel's register allocation (and occupancy)
     for (int base = (int)threadIdx.x; base < C; base += step * VC_FIN_BATCH) {
         float s[VC_FIN_BATCH], q[VC_FIN_BATCH], dg[VC_FIN_BATCH], db[VC_FIN_BATCH];
 #pragma unroll

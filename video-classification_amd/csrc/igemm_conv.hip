@@ -128,14 +128,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
     // BatchNorm statistics: per-lane partial sums over this workgroup's tiles, reduced across lanes and added to
     // the replicated accumulators once, after the tile loop (device-scope float atomics are the expensive part:
     // one set per tile held a 64 -> 256 pointwise conv to half its bandwidth)
-    float st_s[4][4], st_q[4][4], st_h[4][4];  // st_h: the shift of the sums (bn_fin.h), 0 without one
+    f32x4 st_s[4], st_q[4], st_h[4];  // st_h: the shift of the sums (bn_fin.h), 0 without one
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            st_s[a][j] = 0.f, st_q[a][j] = 0.f;
-            st_h[a][j] = (p.stats != nullptr && p.stat_shift != nullptr) ? p.stat_shift[cobase + a * 16 + j] : 0.f;
-        }
+    for (int a = 0; a < 4; ++a) {
+        st_s[a] = st_q[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        st_h[a] = (p.stats != nullptr && p.stat_shift != nullptr) ? *(const f32x4*)(p.stat_shift + cobase + a * 16)
+                                                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     // A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the host caps gridDim.x for single-geometry
     // launches so that all workgroups are resident and own the same number of tiles).
@@ -283,17 +282,28 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
                     }
             }
         }
-        if (p.stats != nullptr) {  // rows beyond M hold exact zeros, which a shift would turn into -shift: skipped
+        if (p.stats != nullptr) {
+            // four channels at a time (packed fp32 adds and fmas): this accumulation sits on the tile's critical path
+            if (m0 + BM <= M) {  // whole tile inside the tensor (uniform): no row tests
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const float v = ooff[b] >= 0 ? acc[a][b][j] - st_h[a][j] : 0.f;
-                        st_s[a][j] += v;
-                        st_q[a][j] += v * v;
+                        const f32x4 v = acc[a][b] - st_h[a];
+                        st_s[a] += v;
+                        st_q[a] += v * v;
                     }
+            } else {  // rows beyond M hold exact zeros, which a shift would turn into -shift: skipped
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (ooff[b] < 0) continue;
+                        const f32x4 v = acc[a][b] - st_h[a];
+                        st_s[a] += v;
+                        st_q[a] += v * v;
+                    }
+            }
         }
 
         // ---- store through LDS: the accumulator layout gives a lane 4 channels (8 bytes) of one position; staged,
@@ -440,6 +450,14 @@ int vc_launch_igemm(const VcIgemmParams& p, int mode, hipStream_t stream) {
                   p.taps[0].src_off == 0 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.Ts == p.Ta && p.Hs == p.Ha &&
                   p.Ws == p.Wa && p.out_w == p.Cn && p.out_h == p.Wa * p.Cn && p.out_t == p.Ha * p.Wa * p.Cn &&
                   p.out_n == p.Ta * p.Ha * p.Wa * p.Cn && getenv("VC_NO_POINTWISE") == nullptr;
+    if (q.pointwise && p.splits <= 1 && p.partial == nullptr && getenv("VC_NO_PW_KERNEL") == nullptr) {
+        VcPwParams w;  // the dense GEMM kernel (pw_conv.hip)
+        w.src = p.src, w.wgt = p.wgt, w.out = p.out + p.out_base, w.stats = p.stats, w.stat_shift = p.stat_shift;
+        w.fin = p.fin, w.ep_params = p.ep_params, w.ep_relu = p.ep_relu;
+        w.ep_res = p.ep_res != nullptr ? p.ep_res + p.out_base : nullptr;
+        w.M = p.M, w.K = p.Cs, w.Cn = p.Cn, w.accumulate = p.accumulate;
+        return vc_launch_pw(w, stream);
+    }
     if (p.Cn % 128 == 0 && p.Cn >= 128) return launch_igemm<128, 128, 0>(q, stream);
     return launch_igemm<64, 256, 0>(q, stream);
 }

@@ -38,6 +38,25 @@ struct VcIgemmParams {
     VcTap taps[32];
 };
 
+// pw_conv.hip: the dense case of the above (one centred tap, unit stride, contiguous rows)
+#ifndef VC_PW_WPE
+#define VC_PW_WPE 3  // waves per SIMD the pointwise kernel's register allocation leaves room for
+#endif
+struct VcPwParams {
+    const bf16* src;  // [M][K]
+    const bf16* wgt;  // [Cn][K]
+    bf16* out;        // [M][Cn]
+    float* stats;
+    const float* stat_shift;
+    VcBnFin fin;
+    const float* ep_params;
+    int ep_relu;
+    const bf16* ep_res;
+    int M, K, Cn;
+    int accumulate;
+};
+int vc_launch_pw(const VcPwParams& p, hipStream_t stream);
+
 struct VcWgradParams {
     const bf16* x;   // [N][Ts][Hs][Ws][Cs]
     const bf16* dy;  // [M][Co]

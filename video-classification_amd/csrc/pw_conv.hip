@@ -1,0 +1,302 @@
+// Pointwise (1x1x1, unit stride) Conv3d forward / data-gradient on bf16 MFMA (gfx950): D[m][co] = sum_k X[m][k] W[co][k].
+//
+// The same tile as the implicit-GEMM kernel (igemm_conv.hip: LDS-DMA operand tiles with a source-side XOR swizzle,
+// v_mfma_f32_16x16x32_bf16, output staged through LDS into whole channels-last rows, BatchNorm sums in the epilogue),
+// stripped of everything a dense GEMM does not need -- tap tables, bounds masks, stride-parity classes, split-K, the
+// row table -- because the Bottleneck's pointwise convs are bandwidth-bound and what limits a bandwidth-bound kernel
+// is the bytes it keeps in flight: the general kernel holds ~230 VGPRs (two workgroups per CU); this one is built for
+// WPE waves per SIMD so that three or four workgroups fit, each with its tile's loads outstanding.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int ROWB = BK * 2;
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __attribute__((aligned(128))) unsigned int vc_pw_zero_page[32];
+
+template <int BCO, int BM>
+struct PwCfg {
+    static constexpr int WCO = BCO / 64, WM = BM / 64;
+    static constexpr int NX = BM / 32, NW = BCO / 32;
+    static constexpr int BUF_BYTES = (BCO + BM) * ROWB;
+    static constexpr int STAGE_BYTES = BM * (BCO * 2 + 16);
+    static constexpr int LDS_1 = BUF_BYTES > STAGE_BYTES ? BUF_BYTES : STAGE_BYTES;      // one K chunk per tile
+    static constexpr int LDS_2 = 2 * BUF_BYTES > STAGE_BYTES ? 2 * BUF_BYTES : STAGE_BYTES;  // double buffered
+    static_assert(WCO * WM == 4, "4 waves per workgroup");
+};
+
+template <int BCO, int BM, int WPE>
+__global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
+    using Cfg = PwCfg<BCO, BM>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * BCO;
+    const int lrow = tid >> 3;
+    const int lslot = (tid & 7) ^ ((lrow >> 1) & 7);
+    const int wco = wave % Cfg::WCO, wm = wave / Cfg::WCO;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int lswz = (lane >> 1) & 7;
+    const int cobase = co0 + wco * 64 + lg * 4;
+    const int nchunks = p.K >> 6;
+    const int ntiles = (p.M + BM - 1) / BM;
+    const gptr_t zero = (gptr_t)vc_pw_zero_page;
+    // byte offsets from the (uniform) tensor bases, 32 bits each: scalar base + vector offset addressing keeps the
+    // loader's state at one register per piece (a tensor stays below 2^31 elements, the C ABI splits the batch above)
+    const unsigned woff = (unsigned)((co0 + lrow) * p.K + lslot * 8) * 2u;  // + j * 32 * K * 2 per piece
+    const char* const wbase = (const char*)p.wgt;
+    const char* const xbase = (const char*)p.src;
+
+    f32x4 st_s[4], st_q[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) st_s[a] = st_q[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * BM;
+        auto issue_chunk = [&](int c, int buf) {
+            char* bW = smem + buf * Cfg::BUF_BYTES + wave * (8 * ROWB);
+            char* bX = bW + BCO * ROWB;
+#pragma unroll
+            for (int j = 0; j < Cfg::NW; ++j)
+                __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (woff + (unsigned)(j * 32 * p.K + c * 64) * 2u)),
+                                                 (lptr_t)(bW + j * 32 * ROWB), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < Cfg::NX; ++i) {
+                const int m = m0 + i * 32 + lrow;
+                const unsigned off = (unsigned)(m * p.K + lslot * 8 + c * 64) * 2u;
+                const gptr_t src = m < p.M ? (gptr_t)(xbase + off) : zero;
+                __builtin_amdgcn_global_load_lds(src, (lptr_t)(bX + i * 32 * ROWB), 16, 0, 0);
+            }
+        };
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        issue_chunk(0, 0);
+        int buf = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            __syncthreads();  // chunk c has landed; the other buffer was read one iteration ago
+            if (c + 1 < nchunks) issue_chunk(c + 1, buf ^ 1);
+            const char* sW = smem + buf * Cfg::BUF_BYTES;
+            const char* sX = sW + BCO * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fb[4];
+                const int slot = ((ks << 2) + lg) ^ lswz;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    fb[b] = *(const bf16x8*)(sX + (wm * 64 + b * 16 + l15) * ROWB + (slot << 4));
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const bf16x8 fa = *(const bf16x8*)(sW + (wco * 64 + a * 16 + l15) * ROWB + (slot << 4));
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[b], acc[a][b], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+
+        // ---- epilogue: acc[a][b][j] = D[co = cobase + a*16 + j][m = m0 + wm*64 + b*16 + l15]
+        if (p.ep_params != nullptr) {  // inference: BatchNorm scale / shift (+ ReLU) on the fp32 accumulators
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 s4 = *(const f32x4*)(p.ep_params + 2 * p.Cn + cobase + a * 16);
+                const f32x4 h4 = *(const f32x4*)(p.ep_params + 3 * p.Cn + cobase + a * 16);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    f32x4 v = acc[a][b] * s4 + h4;
+                    if (p.ep_relu && p.ep_res == nullptr) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    }
+                    acc[a][b] = v;
+                }
+            }
+        }
+        if (p.stats != nullptr) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 sh = p.stat_shift != nullptr ? *(const f32x4*)(p.stat_shift + cobase + a * 16)
+                                                         : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (m0 + BM > p.M && m0 + wm * 64 + b * 16 + l15 >= p.M) continue;  // zero rows beyond M: no -shift
+                    const f32x4 v = acc[a][b] - sh;
+                    st_s[a] += v;
+                    st_q[a] += v * v;
+                }
+            }
+        }
+        constexpr int OPITCH = BCO * 2 + 16;
+        constexpr int PPR = BCO / 8;
+        __syncthreads();  // every wave has finished reading the operand tiles
+        const bf16* addsrc = p.ep_res != nullptr ? p.ep_res : (p.accumulate ? p.out : nullptr);
+        if (addsrc != nullptr) {
+            for (int i = tid; i < BM * PPR; i += 256) {
+                const int r = i / PPR, c8 = i - r * PPR;
+                if (m0 + r < p.M)
+                    *(bf16x8*)(smem + r * OPITCH + c8 * 16) = *(const bf16x8*)(addsrc + (size_t)(m0 + r) * p.Cn + co0 + c8 * 8);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                bf16x4* q = (bf16x4*)(smem + (wm * 64 + b * 16 + l15) * OPITCH + (wco * 64 + a * 16 + lg * 4) * 2);
+                f32x4 v = acc[a][b];
+                if (addsrc != nullptr) {
+                    const bf16x4 old = *q;
+                    v[0] += bf2f(old[0]), v[1] += bf2f(old[1]), v[2] += bf2f(old[2]), v[3] += bf2f(old[3]);
+                    if (p.ep_res != nullptr && p.ep_relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    }
+                }
+                bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *q = o;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < BM * PPR; i += 256) {
+            const int r = i / PPR, c8 = i - r * PPR;
+            if (m0 + r < p.M)
+                *(bf16x8*)(p.out + (size_t)(m0 + r) * p.Cn + co0 + c8 * 8) = *(const bf16x8*)(smem + r * OPITCH + c8 * 16);
+        }
+        __syncthreads();  // the staged tile has been read out before the next tile's operands land on it
+    }
+
+    if (p.stats != nullptr) {
+        float* sred = (float*)smem;  // [WM][2][BCO]
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float ss = st_s[a][j], qq = st_q[a][j];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    ss += __shfl_xor(ss, o);
+                    qq += __shfl_xor(qq, o);
+                }
+                if (l15 == 0) {
+                    sred[(wm * 2 + 0) * BCO + wco * 64 + a * 16 + lg * 4 + j] = ss;
+                    sred[(wm * 2 + 1) * BCO + wco * 64 + a * 16 + lg * 4 + j] = qq;
+                }
+            }
+        }
+        __syncthreads();
+        float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
+        for (int i = tid; i < 2 * BCO; i += 256) {
+            const int mom = i / BCO, c = i - mom * BCO;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < Cfg::WM; ++w) v += sred[(w * 2 + mom) * BCO + c];
+            atomicAdd(srep + mom * p.Cn + co0 + c, v);
+        }
+    }
+    // ---- BatchNorm finalize, per co block: the sums of channels [co0, co0 + BCO) are complete when the last of the
+    // gridDim.x workgroups that share blockIdx.y has added its share, so THAT workgroup finalizes them (ticket word
+    // blockIdx.y; bn_fin.h explains the memory-ordering side).  The tail is one round of loads whatever Cn is -- the
+    // whole-layer form (one workgroup, Cn / 256 dependent rounds) cost a 2048-channel layer 11 us -- and it needs few
+    // registers: unrolled over channels it had set this kernel's allocation at 248 VGPRs, i.e. its occupancy.
+    if (p.fin.ticket == nullptr || p.stats == nullptr) return;
+    // (the flag lives in the dynamic LDS block: a static __shared__ word on top of 2 x 40 KB of operand buffers would
+    // put the 64 x 256 form past the 80 KB it asks for)
+    volatile unsigned* s_last_p = (volatile unsigned*)(smem + 8192);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's atomics have been performed
+    __syncthreads();  // also: every thread is done with the reduction scratch at the head of smem
+    if (tid == 0) {
+        unsigned last = 0u;
+        const unsigned t = __hip_atomic_fetch_add(p.fin.ticket + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1u) {
+            __hip_atomic_store(p.fin.ticket + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = 1u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *s_last_p = last;
+    }
+    __syncthreads();
+    if (*s_last_p == 0u) return;
+    float* sfin = (float*)smem;  // [2][BCO]: sum and sum of squares over the replicas, in replica order
+    if (tid < 2 * BCO) {
+        const int mom = tid / BCO, c = co0 + (tid - mom * BCO);
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < VC_STAT_REPLICAS; ++r)
+            v += vc_stat_load<true>(p.stats + (size_t)r * 2 * p.Cn + mom * p.Cn + c);
+        sfin[tid] = v;
+    }
+    __syncthreads();
+    if (tid < BCO) {
+        const VcBnFin& f = p.fin;
+        const int c = co0 + tid, C = p.Cn;
+        const float m1 = sfin[tid] / f.count;
+        const float mean = (f.shift != nullptr ? f.shift[c] : 0.f) + m1;
+        float var = sfin[BCO + tid] / f.count - m1 * m1;
+        var = var > 0.f ? var : 0.f;
+        if (f.shift_out != nullptr) f.shift_out[c] = mean;
+        const float invstd = rsqrtf(var + f.eps);
+        const float scale = f.gamma[c] * invstd;
+        f.params[c] = mean;
+        f.params[C + c] = invstd;
+        f.params[2 * C + c] = scale;
+        f.params[3 * C + c] = f.beta[c] - mean * scale;
+        if (f.running_mean != nullptr) {
+            const float unbiased = f.count > 1.f ? var * f.count / (f.count - 1.f) : var;
+            f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+        }
+    }
+}
+
+template <int BCO, int BM, int WPE>
+int launch_pw(const VcPwParams& p, hipStream_t stream) {
+    using Cfg = PwCfg<BCO, BM>;
+    const bool one_chunk = p.K == 64;
+    const int lds = one_chunk ? Cfg::LDS_1 : Cfg::LDS_2;
+    dim3 grid((p.M + BM - 1) / BM, p.Cn / BCO, 1);
+    // persistent over tiles: all workgroups resident, same tile count each (the BatchNorm sums stay in registers)
+    long per_cu = 160 * 1024 / lds;
+    if (per_cu > WPE) per_cu = WPE;
+    const long resident = 256l * per_cu;
+    const long cap_x = resident / grid.y > 0 ? resident / grid.y : 1;
+    if ((long)grid.x > cap_x) {
+        const long per = ((long)grid.x + cap_x - 1) / cap_x;
+        grid.x = (unsigned)(((long)grid.x + per - 1) / per);
+    }
+    if (lds > 64 * 1024) {
+        static VcPerDeviceOnce once;
+        once.run([&] {
+            (void)hipFuncSetAttribute((const void*)pw_kernel<BCO, BM, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_2);
+        });
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((pw_kernel<BCO, BM, WPE>), grid, dim3(256), lds, stream, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        vc_set_error("pointwise conv launch failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+int vc_launch_pw(const VcPwParams& p, hipStream_t stream) {
+    if (p.M <= 0) return 0;
+    if (p.Cn % 64 != 0 || p.K % 64 != 0) {
+        vc_set_error("pointwise conv: channels must be multiples of 64 (Cn=%d K=%d)", p.Cn, p.K);
+        return -2;
+    }
+    if (p.Cn % 128 == 0) return launch_pw<128, 128, VC_PW_WPE>(p, stream);
+    return launch_pw<64, 256, VC_PW_WPE>(p, stream);
+}
