@@ -283,3 +283,26 @@ def test_bucket_layout_single_process():
         red.on_ready(k)
     red.finish()
     assert calls == [80, 20]
+
+
+def test_c_abi_host_code_under_sanitizers():
+    """The library's host side (planners, tap-table builders, split and sub-batch logic, argument checks) compiled with
+    AddressSanitizer + UndefinedBehaviorSanitizer (host code only: hipcc -Xarch_host -fsanitize=...) and driven through
+    every conv / stem / pool / BatchNorm entry point of include/vc3d.h for the R3D-18/34/50 layer geometries at the
+    BASELINE clip sizes, a ragged clip, the T = 1 reference geometry and the refused shapes (tests/abi_host_check.cpp).
+    There is no GPU here: every launch fails with a message after its host-side set-up has run; the check is that no
+    call crashes and neither sanitizer reports (UBSan is built to abort).  First run builds the binary (~20 s)."""
+    import shutil
+    import subprocess
+    if shutil.which("make") is None or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("needs make and hipcc")
+    csrc = os.path.join(ROOT, "video-classification_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "-j8", "hostcheck"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # (verify_asan_link_order=0: the environment may preload a library of its own ahead of the sanitizer runtime)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(csrc, "build_asan", "abi_host_check")], capture_output=True, text=True, timeout=300,
+                       env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.stdout.startswith("calls ") and int(r.stdout.split()[1].rstrip(",")) > 5000
