@@ -17,6 +17,9 @@ python3 scripts/prof_summary.py $O/trace50/p_results.db --steps 13 --top 70 --cs
 step "pmc" && bash scripts/pmc_check.sh $TAG > $O/pmc.log 2>&1 || { tail -5 $O/pmc.log; exit 1; }
 python3 scripts/pmc_summary.py gpurun_out/pmc_$TAG --csv $O/pmc_per_kernel.csv > $O/pmc_summary.txt
 python3 scripts/roofline_table.py $O/kernel_stats.csv $O/pmc_per_kernel.csv > $O/roofline_table.txt
+step "pmc R3D-50" && bash scripts/pmc_check.sh ${TAG}_r50 --model 50 > $O/pmc_r50.log 2>&1 || { tail -5 $O/pmc_r50.log; exit 1; }
+python3 scripts/pmc_summary.py gpurun_out/pmc_${TAG}_r50 --csv $O/pmc_per_kernel_r3d50.csv > $O/pmc_summary_r3d50.txt
+python3 scripts/roofline_table.py $O/kernel_stats_r3d50.csv $O/pmc_per_kernel_r3d50.csv > $O/roofline_table_r3d50.txt
 step "other configs" && {
   timeout -k 10 300 python3 bench.py --model 50 --classes 400 --eval --no-cpu-baseline 2>/dev/null
   timeout -k 10 300 python3 bench.py --model 18 --eval --no-cpu-baseline 2>/dev/null
@@ -24,5 +27,5 @@ step "other configs" && {
   timeout -k 10 400 python3 bench.py --model 50 --clip-len 64 --crop 224 --classes 400 --batch 64 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null
 } > $O/bench_other_configs.jsonl
 step "host enqueue" && timeout -k 10 200 python3 scripts/cpu_enqueue.py > $O/cpu_enqueue.txt 2>&1
-rm -rf $O/trace18 $O/trace50 gpurun_out/pmc_$TAG/*/p_results.db 2>/dev/null
+rm -rf $O/trace18 $O/trace50 gpurun_out/pmc_$TAG/*/p_results.db gpurun_out/pmc_${TAG}_r50/*/p_results.db 2>/dev/null
 ls $O

@@ -292,14 +292,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_wgrad_kernel(const float* _
     bool on = i < n4;
     if (on && live != 0xffffffffu) on = ((live >> (unsigned)((i / ci4) % taps)) & 1u) != 0u;
     if (on) {
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+        // four independent chains per thread: the walk is a chain of memory latencies, not of bytes
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
         int z = q;
-        for (; z + PH < splits; z += 2 * PH) {
-            s += ((const f32x4*)(slabs + (size_t)z * stride))[i];
-            s1 += ((const f32x4*)(slabs + (size_t)(z + PH) * stride))[i];
+        for (; z + 3 * PH < splits; z += 4 * PH) {
+            const f32x4 v0 = ((const f32x4*)(slabs + (size_t)z * stride))[i];
+            const f32x4 v1 = ((const f32x4*)(slabs + (size_t)(z + PH) * stride))[i];
+            const f32x4 v2 = ((const f32x4*)(slabs + (size_t)(z + 2 * PH) * stride))[i];
+            const f32x4 v3 = ((const f32x4*)(slabs + (size_t)(z + 3 * PH) * stride))[i];
+            s += v0, s1 += v1, s2 += v2, s3 += v3;
         }
-        if (z < splits) s += ((const f32x4*)(slabs + (size_t)z * stride))[i];
+        for (; z < splits; z += PH) s += ((const f32x4*)(slabs + (size_t)z * stride))[i];
         s += s1;
+        s2 += s3;
+        s += s2;
     }
     if (q > 0) part[q - 1][l] = s;
     __syncthreads();
