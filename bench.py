@@ -144,7 +144,7 @@ def family_rooflines(table):
             if k == 27 and s == 1:
                 name = "wgrad9_kernel (3x3x3 stride-1 wgrad)" if kind == "wgrad" else "halo_conv_kernel (3x3x3 stride-1 fwd+dgrad)"
             elif k == 1:
-                name = "1x1x1 convs (igemm_kernel / wgrad_kernel, HBM-bound)"
+                name = "1x1x1 convs (pw_kernel / igemm_kernel / wgrad_kernel, HBM-bound)"
             else:
                 name = "strided convs (igemm_kernel / wgrad_kernel)"
         f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
