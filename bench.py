@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=0, help="timed oracle steps of the cpu_baseline leg (0: as many as fit ~12 s)")
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--eval", action="store_true", help="forward-only (valid.py path) throughput")
+    ap.add_argument("--optimizer", default="sgd", choices=("sgd", "adam"), help="TRAIN.OPTIMIZER (reference default: adam)")
     return ap.parse_args()
 
 
@@ -199,7 +200,7 @@ def main():
     cfg.MODEL.RESNET_TYPE = args.model
     cfg.MODEL.CLFDIM = args.classes or (101 if args.model == 18 else 400)
     cfg.MODEL.INIT_WEIGHTS = False
-    cfg.TRAIN.OPTIMIZER = "sgd"
+    cfg.TRAIN.OPTIMIZER = args.optimizer
     cfg.TRAIN.LR = 0.001
     torch.manual_seed(0)
     model = create_model(cfg, is_train=True).to(dev)
@@ -301,9 +302,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "3D-ResNet-%d %s, synthetic %dx%dx%d clips, %d classes, batch %d per GPU, "
-                                   "SGD momentum" % (args.model, "forward-only" if args.eval else "bf16 training",
-                                                     args.clip_len, args.crop, args.crop, cfg.MODEL.CLFDIM,
-                                                     args.batch),
+                                   "%s" % (args.model, "forward-only" if args.eval else "bf16 training",
+                                           args.clip_len, args.crop, args.crop, cfg.MODEL.CLFDIM, args.batch,
+                                           "SGD momentum" if args.optimizer == "sgd" else "Adam"),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": roof,
             # the kernel FAMILY with the largest aggregate share of the step's conv time (one warm-up step with every

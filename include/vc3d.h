@@ -124,6 +124,12 @@ int vc_pack_weight(const float* w_master, void* w_fwd, void* w_dgrad /* nullable
 int vc_sgd_step(float* params, const float* grads, float* momentum_buf /* nullable */,
                 void* shadow_bf16 /* nullable */, int64_t n, float lr, float momentum, float weight_decay,
                 int32_t nesterov, void* stream);
+/* torch.optim.Adam's step (the reference's DEFAULT optimizer: config.py:43, utils.py:30-33; betas / eps as passed,
+ * amsgrad off) over the same flat buffers, one launch, also writing the bf16 shadow.  `step` = 1 for the first call
+ * (bias corrections 1 - beta^step are taken on the host in double, as torch does); exp_avg / exp_avg_sq start at zero. */
+int vc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16 /* nullable */,
+                 int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                 void* stream);
 int vc_shadow_bf16(const float* params, void* shadow_bf16, int64_t n, void* stream);
 int vc_pack_dgrad_batched(const void* shadow_bf16, void* w_dgrad_flat, const int32_t* table_dev,
                           const int32_t* table_host, int32_t nconv, void* stream);

@@ -102,6 +102,9 @@ static void net(int depth, int N, int T, int HW) {
             cin = cout, t = to, hw = ho;
         }
     }
+    note(vc_sgd_step(F, F, F, P, 1000003, 0.1f, 0.9f, 1e-4f, 1, nullptr));
+    note(vc_adam_step(F, F, F, F, P, 1000003, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 7, nullptr));
+    note(vc_adam_step(F, F, F, F, P, 16, 1e-3f, 1.0f, 0.999f, 1e-8f, 0.f, 1, nullptr));  // refused: beta1 = 1
     note(vc_gavgpool_fwd(P, F, N, t * hw * hw, cin, nullptr));
     note(vc_linear_fwd(F, F, F, F, N, cin, 400, nullptr));
 }

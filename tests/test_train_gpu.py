@@ -127,6 +127,56 @@ def test_flat_sgd_matches_torch_sgd(nesterov):
     assert torch.isfinite(loss)
 
 
+def test_flat_adam_matches_torch_adam():
+    """create_optimizer's 'adam' (the reference's default optimizer, config.py:43, utils.py:30-33) on the GPU is the
+    fused flat step (vc_adam_step): against torch.optim.Adam(lr) on the same gradients, three steps (both moments and
+    the bias corrections carry over); the packed bf16 operands follow the new weights; state_dict round trip."""
+    from models.model import create_model
+    from utils.utils import create_optimizer
+    from vc3d.optim import FlatAdam
+    from vc3d import ops
+    torch.manual_seed(0)
+    cfg = make_config(18, 7, OPTIMIZER="adam", LR=1e-3)
+    model = create_model(cfg, True).cuda().train()
+    opt = create_optimizer(cfg, model)
+    assert isinstance(opt, FlatAdam)
+    x = torch.randn(4, 3, 4, 32, 32).cuda()
+    y = torch.randint(0, 7, (4,)).cuda()
+    _, score, _ = model(x)
+    F.cross_entropy(score, y).backward()
+    names = [n for n, _ in model.named_parameters()]
+    ref = [p.detach().cpu().clone().requires_grad_() for p in model.parameters()]
+    for r, p in zip(ref, model.parameters()):
+        r.grad = p.grad.detach().cpu().clone()
+    topt = torch.optim.Adam(ref, lr=1e-3)
+    for _ in range(3):
+        opt.step()
+        topt.step()
+    torch.cuda.synchronize()
+    for n, r, p in zip(names, ref, model.parameters()):
+        assert torch.allclose(p.detach().cpu(), r.detach(), rtol=2e-5, atol=2e-6), n
+    eng = model.backbone.engine
+    for cb in eng.all_convbn():
+        if cb is eng.stem:
+            continue
+        wf, wd = ops.pack_weight(cb.conv.weight)
+        assert torch.equal(cb.wf, wf) and torch.equal(cb.wd, wd), cb.name
+    sd = opt.state_dict()
+    opt2 = create_optimizer(cfg, model)
+    opt2.load_state_dict(sd)
+    assert opt2.steps == 3 and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    # training continues: the loss of a fixed batch falls over a few Adam steps
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        _, score, _ = model(x)
+        loss = F.cross_entropy(score, y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+
+
 def test_train_and_validate_on_raw_uint8_frames(monkeypatch):
     """the loops take decoded uint8 frames; ChooseInput samples / crops / normalises them on the
     GPU (vc_clip_pack_u8) and the model consumes the packed clips directly."""

@@ -1,6 +1,7 @@
 // extern "C" entry points of libvc3d.so (declared in include/vc3d.h): validate shapes on the
 // host, build the gather descriptions and launch.  Nothing here allocates or synchronises.
 #include <stdarg.h>
+#include <cmath>
 #include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
@@ -673,6 +674,17 @@ int vc_sgd_step(float* params, const float* grads, float* momentum_buf, void* sh
     VC_REQUIRE(!nesterov || (momentum_buf && momentum > 0.f), "sgd_step: nesterov needs momentum");
     return vc_ew_sgd_step(params, grads, momentum_buf, shadow_bf16, (long)n, lr, momentum, weight_decay, nesterov,
                           S(stream));
+}
+int vc_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream) {
+    VC_REQUIRE(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad arguments");
+    VC_REQUIRE(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0 &&
+                   (uintptr_t)shadow_bf16 % 8 == 0,
+               "adam_step: buffers must be 16-byte aligned");
+    VC_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "adam_step: bad betas / eps");
+    const double bias1 = 1.0 - pow((double)beta1, (double)step), bias2 = 1.0 - pow((double)beta2, (double)step);
+    return vc_ew_adam_step(params, grads, exp_avg, exp_avg_sq, shadow_bf16, (long)n, (float)((double)lr / bias1), beta1, beta2,
+                           eps, weight_decay, (float)sqrt(bias2), S(stream));
 }
 int vc_shadow_bf16(const float* params, void* shadow_bf16, int64_t n, void* stream) {
     VC_REQUIRE(params && shadow_bf16 && n > 0, "shadow_bf16: bad arguments");

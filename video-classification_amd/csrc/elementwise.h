@@ -54,6 +54,8 @@ int vc_ew_stem_pack_weight(const float* w, void* ws, int Co, hipStream_t s);
 int vc_ew_stem_unpack_wgrad(const float* dws, float* dw, int Co, hipStream_t s);
 int vc_ew_sgd_step(float* p, const float* g, float* mom, void* shadow, long n, float lr, float momentum, float wd,
                    int nesterov, hipStream_t s);
+int vc_ew_adam_step(float* p, const float* g, float* m, float* v, void* shadow, long n, float step_size, float b1, float b2,
+                    float eps, float wd, float bias2_sqrt, hipStream_t s);
 int vc_ew_shadow(const float* p, void* shadow, long n, hipStream_t s);
 int vc_ew_pack_dgrad_batched(const void* shadow, void* wd, const int* table, int nconv, int tiles, hipStream_t s);
 int vc_ew_bn_bwd_reduce_pooled(const void* y, const void* dout, const uint8_t* idx, const void* pooled, const float* params,

@@ -1263,6 +1263,39 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, co
     }
 }
 
+// torch.optim.Adam's step (amsgrad off, maximize off) over the flat buffers, one launch for the whole model, in the
+// order torch applies it: g += wd p; m += (1 - b1)(g - m)  [lerp]; v = b2 v + (1 - b2) g g;
+// p -= (lr / bias1) m / (sqrt(v) / sqrt(bias2) + eps); also writes the bf16 shadow.  bias1 = 1 - b1^t and
+// sqrt(bias2) = sqrt(1 - b2^t) come from the host (step count t), as torch computes them.
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        bf16* __restrict__ shadow, long n, float step_size, float b1,
+                                                        float b2, float eps, float wd, float bias2_sqrt) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride * 4) {
+        if (i + 4 <= n) {
+            f32x4 pv = *(const f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(const f32x4*)(m + i),
+                  vv = *(const f32x4*)(v + i);
+            gv += wd * pv;
+            mv += (1.f - b1) * (gv - mv);
+            vv = b2 * vv + (1.f - b2) * gv * gv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pv[k] -= step_size * (mv[k] / (sqrtf(vv[k]) / bias2_sqrt + eps));
+            *(f32x4*)(p + i) = pv, *(f32x4*)(m + i) = mv, *(f32x4*)(v + i) = vv;
+            if (shadow != nullptr) *(bf16x4*)(shadow + i) = (bf16x4){f2bf(pv[0]), f2bf(pv[1]), f2bf(pv[2]), f2bf(pv[3])};
+        } else {
+            for (long j = i; j < n; ++j) {
+                float pv = p[j], gv = g[j] + wd * p[j], mv = m[j], vv = v[j];
+                mv += (1.f - b1) * (gv - mv);
+                vv = b2 * vv + (1.f - b2) * gv * gv;
+                pv -= step_size * (mv / (sqrtf(vv) / bias2_sqrt + eps));
+                p[j] = pv, m[j] = mv, v[j] = vv;
+                if (shadow != nullptr) shadow[j] = f2bf(pv);
+            }
+        }
+    }
+}
+
 // fp32 -> bf16 copy of the flat parameters (after a checkpoint load, or with a non-fused optimizer)
 __global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ p, bf16* __restrict__ shadow, long n) {
     const long stride = (long)gridDim.x * blockDim.x;
@@ -1581,6 +1614,12 @@ int vc_ew_sgd_step(float* p, const float* g, float* mom, void* shadow, long n, f
                    int nesterov, hipStream_t s) {
     VC_LAUNCH(sgd_step_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, s, p, g, mom, (bf16*)shadow, n, lr,
               momentum, wd, nesterov);
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_adam_step(float* p, const float* g, float* m, float* v, void* shadow, long n, float step_size, float b1, float b2,
+                    float eps, float wd, float bias2_sqrt, hipStream_t s) {
+    VC_LAUNCH(adam_step_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, s, p, g, m, v, (bf16*)shadow, n,
+              step_size, b1, b2, eps, wd, bias2_sqrt);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_shadow(const float* p, void* shadow, long n, hipStream_t s) {

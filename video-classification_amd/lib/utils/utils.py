@@ -17,6 +17,9 @@ def create_optimizer(cfg, model):
     if name == 'sgd':
         return torch.optim.SGD(params, lr=cfg.TRAIN.LR, momentum=cfg.TRAIN.MOMENTUM,
                                weight_decay=cfg.TRAIN.WD, nesterov=cfg.TRAIN.NESTEROV)
+    if name == 'adam' and _fusable(model):
+        from vc3d.optim import FlatAdam  # same arithmetic as torch.optim.Adam (default betas / eps), one launch
+        return FlatAdam(model, lr=cfg.TRAIN.LR)
     if name == 'adam':
         return torch.optim.Adam(params, lr=cfg.TRAIN.LR)
     return None

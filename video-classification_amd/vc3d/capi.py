@@ -75,6 +75,7 @@ PROTOTYPES = {
     "vc_conv3d_wgrad": [_CD, _P, _P, _P, _P, C.c_size_t, _P],
     "vc_pack_weight": [_P, _P, _P, _I, _I, _I, _P],
     "vc_sgd_step": [_P, _P, _P, _P, _L, _F, _F, _F, _I, _P],
+    "vc_adam_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _P],
     "vc_shadow_bf16": [_P, _P, _L, _P],
     "vc_pack_dgrad_batched": [_P, _P, _P, _P, _I, _P],
     "vc_stem_packed_input_elems": [_I, _I, _I, _I],

@@ -201,6 +201,16 @@ def sgd_step(params, grads, mom, shadow, lr, momentum, wd, nesterov):
                           1 if nesterov else 0, cur_stream()), "vc_sgd_step")
 
 
+def adam_step(params, grads, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, wd, step):
+    """fused torch.optim.Adam step over flat fp32 buffers (step counts from 1); also writes the bf16 shadow."""
+    n = params.numel()
+    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, F32, n, nm)
+    _chk(shadow, BF16, n, "shadow")
+    check(lib.vc_adam_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), ptr(shadow), n, float(lr), float(beta1),
+                           float(beta2), float(eps), float(wd), int(step), cur_stream()), "vc_adam_step")
+
+
 def shadow_bf16(params, shadow):
     _chk(params, F32, name="flat params")
     _chk(shadow, BF16, params.numel(), "bf16 shadow")
