@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Tuning aid: per-phase clocks of the wgrad9 kernel (vc_debug_wgrad9_stamps)."""
+"""Tuning aid: per-phase clocks of the wgrad9 kernel (vc_debug_wgrad9_stamps).  The default build records the loop total
+only; the per-phase split needs wgrad9_conv.hip built with -DVC_W9_STAMPS (which puts the phases back into blocks of
+their own)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "video-classification_amd")):

@@ -20,8 +20,10 @@
 // ago, no wait -- and the global loads of chunk c+2 are issued right after, with a whole phase to land.  One barrier
 // per chunk.  The phases outside the MFMAs are exposed (the waves of a workgroup are in the same phase, and the two
 // waves of a SIMD serialise their VALU work), so the staging code is kept lean: 32-bit offsets advanced by a constant
-// per chunk, 32-bit chunk-relative validity tests, no per-segment branches (every thread stores all its segments;
-// the buffers are sized for that), zeros made with a mask.
+// per chunk, 32-bit chunk-relative validity tests, no branches at all (every thread stores all its segments, the
+// buffers are sized for that; zeros made with a mask; the tail iterations stage harmlessly).  Placing the staging
+// between the k-steps of the MFMA stream instead of in front of it was tried and is slower (195k against 185k
+// clocks per layer1 workgroup: it breaks the pinned read / MFMA interleave).
 //
 // Two forms of the same kernel: eight waves with 128-row chunks (one workgroup per CU; wave = co half x ci quarter,
 // 18 MFMA tiles) and four waves with 64-row chunks (two workgroups per CU, which drift apart so that one computes
@@ -197,10 +199,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const int b = c & 1;
         // chunk c+1 (loaded during the previous phase) goes into the other buffer, which was last read before the
         // previous barrier; then the loads of chunk c+2 go out
+#ifndef VC_W9_STAMPS
+        // unconditional (no branches, one basic block with the MFMAs: 204k -> 185k clocks per workgroup at layer1)
+        store_chunk(b ^ 1);  // past the last chunk: stale registers into a buffer nobody reads
+        load_chunk();        // past the last chunk: every segment invalid, loads from offset 0
+#else  // per-phase stamps (scripts/wgrad9_stamps.py; build with -DVC_W9_STAMPS)
         if (c + 1 < nchunks) store_chunk(b ^ 1);
         VC_W9_LAP(2);
         if (c + 2 < nchunks) load_chunk();
         VC_W9_LAP(0);
+#endif
         const unsigned ybase = (unsigned)(sY(b) - smem);
         const unsigned* tab = sT(b);
         const unsigned xcol = (unsigned)(ciw * 16 * NCI + 4 * pp) * 2;  // this lane's column inside an image (or zero) row
@@ -255,7 +263,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
             }
+#ifdef VC_W9_STAMPS
         VC_W9_LAP(1);
+#endif
         __syncthreads();
         VC_W9_LAP(3);
     }
