@@ -68,6 +68,12 @@ def main():
         if "dgrad" in ops_sel:
             ms = timeit(lambda: ops.conv3d_dgrad(d, dy, wd, out=dx))
             line += "  dgrad %.3f ms %6.0f TF" % (ms, flops / ms / 1e9)
+        if "dacc" in ops_sel:  # accumulating dgrad (dx += ...)
+            ms = timeit(lambda: ops.conv3d_dgrad(d, dy, wd, out=dx, accumulate=True))
+            line += "  dgrad+= %.3f ms %6.0f TF" % (ms, flops / ms / 1e9)
+        if "fwdns" in ops_sel:  # forward without the BatchNorm sums
+            ms = timeit(lambda: ops.conv3d_fwd(d, x, wf, out=y))
+            line += "  fwd(no sums) %.3f ms %6.0f TF" % (ms, flops / ms / 1e9)
         if "wgrad" in ops_sel:
             ms = timeit(lambda: ops.conv3d_wgrad(d, x, dy, dw))
             line += "  wgrad %.3f ms %6.0f TF" % (ms, flops / ms / 1e9)

@@ -514,21 +514,37 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     }
     if (p.stats != nullptr) {
+        // four channels at a time (packed fp32), without the per-element slot test when every slot of the wave is a real
+        // position (wave-uniform): this accumulation is exposed -- it cost a layer1 forward 15 us of 134
+        bool anybad = false;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) anybad = anybad || ooff[b] < 0;
+        const bool clean = __builtin_amdgcn_ballot_w64(anybad) == 0;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             f32x4 sh4 = {0.f, 0.f, 0.f, 0.f};  // shifted sums (bn_fin.h)
             if (p.stat_shift != nullptr) sh4 = *(const f32x4*)(p.stat_shift + cobase + a * 16);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float ss = 0.f, qq = 0.f;
+            f32x4 ss4 = {0.f, 0.f, 0.f, 0.f}, qq4 = {0.f, 0.f, 0.f, 0.f};
+            if (clean) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    const float v = ooff[b] >= 0 ? acc[a][b][j] - sh4[j] : 0.f;
-                    ss += v;
-                    qq += v * v;
+                    const f32x4 v = acc[a][b] - sh4;
+                    ss4 += v;
+                    qq4 += v * v;
                 }
-                ss = row16_sum(ss);
-                qq = row16_sum(qq);
+            } else {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if (ooff[b] < 0) continue;
+                    const f32x4 v = acc[a][b] - sh4;
+                    ss4 += v;
+                    qq4 += v * v;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ss = row16_sum(ss4[j]);
+                const float qq = row16_sum(qq4[j]);
                 if (l15 == 0) {
                     sstat[wave * 128 + a * 16 + lg * 4 + j] = ss;
                     sstat[wave * 128 + 64 + a * 16 + lg * 4 + j] = qq;

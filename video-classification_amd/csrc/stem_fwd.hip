@@ -78,15 +78,14 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NT =
     }
     const int aoff = l15 * WPITCH + lg * 16;
 
-    float ssum[4][4], ssq[4][4];  // BatchNorm partial sums of this lane's channels co = a*16 + lg*4 + j
-    float sshift[4][4];           // their shift (bn_fin.h), 0 without one
+    f32x4 ssum[4], ssq[4];  // BatchNorm partial sums of this lane's channels co = a*16 + lg*4 + j (packed fp32 math)
+    f32x4 sshift[4];        // their shift (bn_fin.h), 0 without one
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ssum[a][j] = 0.f, ssq[a][j] = 0.f;
-            sshift[a][j] = (p.stats != nullptr && p.stat_shift != nullptr) ? p.stat_shift[a * 16 + (lane >> 4) * 4 + j] : 0.f;
-        }
+    for (int a = 0; a < 4; ++a) {
+        ssum[a] = ssq[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        sshift[a] = (p.stats != nullptr && p.stat_shift != nullptr) ? *(const f32x4*)(p.stat_shift + a * 16 + (lane >> 4) * 4)
+                                                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     auto issue_plane = [&](int n, int tp, int h0) {
         char* dst = smem + PL_OFF + (tp % NSLOT) * PLB;
@@ -191,12 +190,9 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NT =
                     for (int a = 0; a < 4; ++a) {
                         const f32x4 v = acc[a][f][nt];
                         *(bf16x4*)(dst + a * 16) = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float u = v[j] - sshift[a][j];  // shifted sums (bn_fin.h)
-                            ssum[a][j] += u;
-                            ssq[a][j] += u * u;
-                        }
+                        const f32x4 u = v - sshift[a];  // shifted sums (bn_fin.h)
+                        ssum[a] += u;
+                        ssq[a] += u * u;
                     }
                 }
             }
