@@ -663,6 +663,10 @@ int vc_halo_plan(int NP, int T, int H, int W, int Cs, int Cn, int ntaps, VcHaloP
         const int nchunks = Cs / CK;
         const int PR = CK == 32 ? 16 : 8;
         for (int pad = 0; pad <= (no_pad ? 0 : 1); ++pad) {
+            // the 32-channel forms exist in the padded variant only: their masked variants need more than 256 VGPRs
+            // (100+ spilled), and scratch traffic inside an LDS-DMA loop is both slow and, in one build of the
+            // pointwise kernel, was seen to give wrong results
+            if (CK == 32 && !pad) continue;
             const int BM = NW * NB * 16;
             for (int SEG = 1; SEG <= (HW < BM ? HW : BM); ++SEG) {
                 // segments that are whole (h) rows, whole planes, or an even split of a plane
@@ -778,8 +782,11 @@ int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream) 
         p.taps[i].src_off = t.ot * p.HR + t.oh * (p.pad ? p.Wp : p.W) + t.ow;
     }
     if (plan.CK == 32) {
-        if (plan.NB == 7) return p.pad ? launch_halo<4, 32, true, 7>(p, stream) : launch_halo<4, 32, false, 7>(p, stream);
-        return launch_halo<4, 32, false, 4>(p, stream);
+        if (plan.NB != 7 || !p.pad) {
+            vc_set_error("halo conv: the 32-channel form exists as padded 64 x 112 wave tiles only");
+            return -2;
+        }
+        return launch_halo<4, 32, true, 7>(p, stream);
     }
     if (p.pad) return plan.NW == 8 ? launch_halo<8, 64, true, 4>(p, stream) : launch_halo<4, 64, true, 4>(p, stream);
     return plan.NW == 8 ? launch_halo<8, 64, false, 4>(p, stream) : launch_halo<4, 64, false, 4>(p, stream);
