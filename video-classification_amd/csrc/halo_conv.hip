@@ -663,9 +663,9 @@ int vc_halo_plan(int NP, int T, int H, int W, int Cs, int Cn, int ntaps, VcHaloP
         const int nchunks = Cs / CK;
         const int PR = CK == 32 ? 16 : 8;
         for (int pad = 0; pad <= (no_pad ? 0 : 1); ++pad) {
-            // the 32-channel forms exist in the padded variant only: their masked variants need more than 256 VGPRs
-            // (100+ spilled), and scratch traffic inside an LDS-DMA loop is both slow and, in one build of the
-            // pointwise kernel, was seen to give wrong results
+            // the 32-channel forms exist in the padded variant only (fewer instantiations to keep within the register
+            // budget; the padded 64 x 112 form itself spills ~100 VGPRs at the 256 it may use, which is part of why it
+            // only ties with the eight-wave form: it stays opt-in)
             if (CK == 32 && !pad) continue;
             const int BM = NW * NB * 16;
             for (int SEG = 1; SEG <= (HW < BM ? HW : BM); ++SEG) {
