@@ -107,6 +107,26 @@ int vc_conv3d_fwd_noalloc(const vc_conv3d_desc* d, const void* x, const void* w,
 int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx,
                     int accumulate /* dx += instead of dx = */, void* workspace, size_t ws_bytes,
                     void* stream);
+/* vc_conv3d_dgrad followed by the reduction of the BatchNorm backward that consumes dx.  When dx is the gradient that
+ * reaches `relu(bn(y))` (backbone.py:50-55,88-95) or `relu(bn(y) + residual)` (backbone.py:56-61,97-102: the block's
+ * first conv hands it to the previous block), the next thing the backward does is vc_bn_bwd_reduce_fin(y, dx,
+ * relu_bits, params, sums, rows, C = Ci, mask, ticket, coef, dgamma, dbeta) -- a pass that reads dx back.  This entry
+ * point produces the same sums, coef, dgamma += and dbeta += with the conv: dense (1x1x1, unit stride, unsplit)
+ * geometries take them in the GEMM's epilogue from the tile they are about to write, any other geometry runs the
+ * two launches.  relu_bits given: mask mode 3; null: mask mode 2 (the mask is recomputed from y).  sums must be zero
+ * on entry; accumulate as in vc_conv3d_dgrad (the sums are over the accumulated dx). */
+typedef struct {
+    const void* y;            /* what the BatchNorm normalised: [N*Ti*Hi*Wi][Ci] bf16 */
+    const float* params;      /* [4][Ci] of that BatchNorm */
+    const uint8_t* relu_bits; /* vc_bn_apply_mask's bits of the BatchNorm's output, or null (mask mode 2) */
+    float* sums;              /* [32][2][Ci], zero on entry */
+    uint32_t* ticket;         /* as in vc_bn_fin */
+    float* coef;              /* [2][Ci] */
+    float* dgamma;            /* += nullable */
+    float* dbeta;             /* += nullable */
+} vc_bn_bwd_red;
+int vc_conv3d_dgrad_bnred(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                          const vc_bn_bwd_red* red, void* workspace, size_t ws_bytes, void* stream);
 int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy,
                     float* dw /* fp32 [Co][kt][kh][kw][Ci], += */, void* workspace, size_t ws_bytes,
                     void* stream);

@@ -740,3 +740,61 @@ def test_pointwise_kernel_matches_general_kernel(geom):
         assert torch.equal(a, b)
     for a, b in zip(got[3:], ref[3:]):
         assert rel_l2(a.cpu(), b.cpu()) <= 1e-5
+
+
+@pytest.mark.parametrize("geom", [(64, 64, 8, 28, 28, 256, 1), (4, 128, 4, 14, 14, 512, 1), (3, 256, 2, 7, 7, 1024, 1),
+                                  (2, 512, 1, 4, 4, 2048, 1), (1, 64, 1, 3, 5, 64, 1), (2, 64, 2, 9, 9, 64, 3)])
+@pytest.mark.parametrize("accumulate,use_bits", [(False, True), (True, True), (False, False)])
+def test_dgrad_with_folded_bn_backward_reduction(geom, accumulate, use_bits):
+    """vc_conv3d_dgrad_bnred (dense geometries: the BatchNorm backward sums of the tensor the data-gradient GEMM
+    completes are taken in its epilogue, pw_conv.hip) against the two launches it replaces, vc_conv3d_dgrad +
+    vc_bn_bwd_reduce_fin with the ReLU bits (mask mode 3) or with the mask recomputed from y (mode 2, no residual): the
+    same dx bit for bit, and coef / dgamma / dbeta equal to the order of the float additions (both reduce the ROUNDED
+    dx).  `geom` = the conv (Co -> its input Ci = the BatchNorm's channels); the last one is a 3x3x3 conv, which the
+    entry point runs as the two launches itself."""
+    _need_gpu()
+    from vc3d import ops
+    N, Co, T, H, W, Ci, k = geom
+    d = ops.conv_desc(N, Ci, T, H, W, Co, k, 1, k // 2)
+    M = N * T * H * W
+    g = torch.Generator().manual_seed(Ci + Co + k)
+    dy = torch.randn(N, T, H, W, Co, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(Co, Ci, k, k, k, generator=g) * 0.05).cuda().contiguous(memory_format=torch.channels_last_3d)
+    _, wd = ops.pack_weight(w)
+    base = torch.randn(N, T, H, W, Ci, generator=g).to(torch.bfloat16).cuda()
+    # the BatchNorm whose backward consumes dx: its conv output y, parameters, residual and the bits of its output
+    y = (torch.randn(N, T, H, W, Ci, generator=g) * 1.5 + 0.3).to(torch.bfloat16).cuda()
+    res = torch.randn(N, T, H, W, Ci, generator=g).to(torch.bfloat16).cuda()
+    gamma, beta = (torch.rand(Ci, generator=g) + 0.5).cuda(), torch.randn(Ci, generator=g).cuda()
+    params = ops.bn_finalize(ops.bn_stats(y, Ci), M, gamma, beta, None, None, 0.1, 1e-5)
+    bits = None
+    if use_bits:
+        bits = torch.empty(M * Ci // 8, dtype=torch.uint8, device="cuda")
+        ops.bn_apply(y, params, Ci, residual=res, relu=True, relu_bits=bits)
+    mask = 3 if use_bits else 2
+
+    def run(folded):
+        dx = base.clone() if accumulate else torch.empty_like(base)
+        dgamma, dbeta = torch.full((Ci,), 0.25, device="cuda"), torch.full((Ci,), -0.5, device="cuda")  # += targets
+        coef = torch.empty(2, Ci, device="cuda")
+        ticket = torch.zeros(64, dtype=torch.int32, device="cuda")
+        sums = ops.new_stats(Ci, "cuda")
+        if folded:
+            ops.conv3d_dgrad(d, dy, wd, out=dx, accumulate=accumulate,
+                             bnred=(y, params, bits, sums, ticket, coef, dgamma, dbeta))
+            dyb, gm = ops.bn_bwd(y, dx, params, Ci, dgamma, dbeta, mask=mask, aux=bits, want_g=True, coef=coef, reduced=True)
+        else:
+            ops.conv3d_dgrad(d, dy, wd, out=dx, accumulate=accumulate)
+            dyb, gm = ops.bn_bwd(y, dx, params, Ci, dgamma, dbeta, mask=mask, aux=bits, want_g=True, sums=sums, coef=coef,
+                                 ticket=ticket)
+        torch.cuda.synchronize()
+        assert int(ticket.abs().sum()) == 0
+        return dx, coef, dgamma, dbeta, dyb, gm
+
+    ref = run(False)
+    got = run(True)
+    assert torch.equal(got[0], ref[0])
+    for a, b in zip(got[1:4], ref[1:4]):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max())), float((a - b).abs().max())
+    assert torch.equal(got[5], ref[5])
+    assert rel_l2(got[4].float().cpu(), ref[4].float().cpu()) <= 2e-3  # bf16 outputs of coef that differ in the last bits

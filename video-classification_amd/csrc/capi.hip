@@ -447,8 +447,10 @@ extern "C" {
 static inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 static inline int posmod(int a, int b) { return ((a % b) + b) % b; }
 
-int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
-                    void* workspace, size_t ws_bytes, void* stream) {
+// red (nullable): the BatchNorm backward reduction over dx that the caller wants with it (vc_conv3d_dgrad_bnred);
+// *folded tells whether the conv's own launch has taken it.
+static int conv3d_dgrad_impl(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                             const vc_bn_bwd_red* red, bool* folded, void* workspace, size_t ws_bytes, void* stream) {
     int To, Ho, Wo;
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
@@ -459,8 +461,8 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
         for (int n0 = 0; n0 < d->N; n0 += nb) {
             vc_conv3d_desc sub = *d;
             sub.N = d->N - n0 < nb ? d->N - n0 : nb;
-            rc = vc_conv3d_dgrad(&sub, (const bf16*)dy + n0 * out_s, w_dgrad, (bf16*)dx + n0 * in_s, accumulate, workspace,
-                                 ws_bytes, stream);
+            rc = conv3d_dgrad_impl(&sub, (const bf16*)dy + n0 * out_s, w_dgrad, (bf16*)dx + n0 * in_s, accumulate, nullptr,
+                                   nullptr, workspace, ws_bytes, stream);
             if (rc) return rc;
         }
         return 0;
@@ -470,6 +472,18 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
     const size_t dx_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
     int splits = dgrad_splits(d);
     if (splits > 1 && (workspace == nullptr || ws_bytes < (size_t)splits * dx_e * 4)) splits = 1;
+    if (red != nullptr && splits <= 1 && ntaps_all == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 &&
+        d->ph == 0 && d->pw == 0 && getenv("VC_NO_PW_KERNEL") == nullptr && getenv("VC_NO_POINTWISE") == nullptr &&
+        getenv("VC_NO_BNRED_FOLD") == nullptr) {
+        // a dense GEMM whose epilogue holds the finished dx tile: the reduction rides along (pw_conv.hip)
+        VcPwParams w = {};
+        w.src = (const bf16*)dy, w.wgt = (const bf16*)w_dgrad, w.out = (bf16*)dx;
+        w.M = (int)(dx_e / d->Ci), w.K = d->Co, w.Cn = d->Ci, w.accumulate = accumulate;
+        w.red_y = (const bf16*)red->y, w.red_params = red->params, w.red_bits = red->relu_bits, w.red_sums = red->sums;
+        w.red_fin = VcBnBwdFin{red->ticket, red->coef, red->dgamma, red->dbeta, (float)w.M};
+        *folded = true;
+        return vc_launch_pw(w, S(stream));
+    }
     // a parity class with no contributing tap gets zeros
     bool need_zero = false;
     if (!accumulate) {
@@ -576,6 +590,24 @@ int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad
         return vc_ew_splitk_finalize((const float*)workspace, splits, (long long)dx_e, dx, accumulate, nullptr,
                                      (long)(dx_e / d->Ci), d->Ci, nullptr, S(stream));
     return 0;
+}
+
+int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                    void* workspace, size_t ws_bytes, void* stream) {
+    return conv3d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, nullptr, workspace, ws_bytes, stream);
+}
+
+int vc_conv3d_dgrad_bnred(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                          const vc_bn_bwd_red* red, void* workspace, size_t ws_bytes, void* stream) {
+    VC_REQUIRE(d && red && red->y && red->params && red->sums && red->ticket && red->coef,
+               "conv3d_dgrad_bnred: y, params, sums, ticket and coef are required");
+    VC_REQUIRE(pow2_channels(d->Ci), "bn: C=%d must be a power of two in [64, 2048]", d->Ci);
+    bool folded = false;
+    const int rc = conv3d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, red, &folded, workspace, ws_bytes, stream);
+    if (rc || folded) return rc;
+    const int64_t rows = (int64_t)d->N * d->Ti * d->Hi * d->Wi;
+    return vc_bn_bwd_reduce_fin(red->y, dx, red->relu_bits, red->params, red->sums, rows, d->Ci, red->relu_bits ? 3 : 2,
+                                red->ticket, red->coef, red->dgamma, red->dbeta, stream);
 }
 
 int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy, float* dw, void* workspace,

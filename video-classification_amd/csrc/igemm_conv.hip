@@ -451,7 +451,7 @@ int vc_launch_igemm(const VcIgemmParams& p, int mode, hipStream_t stream) {
                   p.Ws == p.Wa && p.out_w == p.Cn && p.out_h == p.Wa * p.Cn && p.out_t == p.Ha * p.Wa * p.Cn &&
                   p.out_n == p.Ta * p.Ha * p.Wa * p.Cn && getenv("VC_NO_POINTWISE") == nullptr;
     if (q.pointwise && p.splits <= 1 && p.partial == nullptr && getenv("VC_NO_PW_KERNEL") == nullptr) {
-        VcPwParams w;  // the dense GEMM kernel (pw_conv.hip)
+        VcPwParams w = {};  // the dense GEMM kernel (pw_conv.hip)
         w.src = p.src, w.wgt = p.wgt, w.out = p.out + p.out_base, w.stats = p.stats, w.stat_shift = p.stat_shift;
         w.fin = p.fin, w.ep_params = p.ep_params, w.ep_relu = p.ep_relu;
         w.ep_res = p.ep_res != nullptr ? p.ep_res + p.out_base : nullptr;

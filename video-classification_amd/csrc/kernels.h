@@ -54,6 +54,16 @@ struct VcPwParams {
     const bf16* ep_res;
     int M, K, Cn;
     int accumulate;
+    // The reduction of a BatchNorm backward folded into the (data-gradient) launch that completes its incoming
+    // gradient: out is the gradient reaching `relu(bn(red_y) [+ residual])`; the epilogue adds sum g and sum g * xhat
+    // over its tile (g = out where the ReLU passed, xhat = (red_y - mean) * invstd) to red_sums -- what
+    // chan_reduce_kernel<1, 3 or 2> would re-read out, red_y and the mask for.  red_sums nullable (with stats == nullptr
+    // only); red_fin as fin.
+    const bf16* red_y;          // [M][Cn]
+    const float* red_params;    // [4][Cn]
+    const uint8_t* red_bits;    // [M * Cn / 8] (mask mode 3), or null: scale * red_y + shift > 0 (mask mode 2)
+    float* red_sums;            // [VC_STAT_REPLICAS][2][Cn]
+    VcBnBwdFin red_fin;
 };
 int vc_launch_pw(const VcPwParams& p, hipStream_t stream);
 

@@ -30,7 +30,8 @@ struct PwCfg {
     static_assert(WCO * WM == 4, "4 waves per workgroup");
 };
 
-template <int BCO, int BM, int WPE>
+// RED: the instantiation that carries the folded BatchNorm backward reduction instead of the forward statistics
+template <int BCO, int BM, int WPE, bool RED>
 __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
     using Cfg = PwCfg<BCO, BM>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -56,6 +57,12 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
     f32x4 st_s[4], st_q[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) st_s[a] = st_q[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // RED: the copy-out's decomposition of a tile -- PPR 16-byte pieces per row, thread = (piece rc8, row lane rr0)
+    constexpr int PPR = BCO / 8, RSTEP = 256 / PPR, NIT = BM / RSTEP;
+    const int rc8_ = tid % PPR, rr0_ = tid / PPR;
+    float ra0[8], ra1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ra0[k] = ra1[k] = 0.f;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * BM;
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
         }
 
         // ---- epilogue: acc[a][b][j] = D[co = cobase + a*16 + j][m = m0 + wm*64 + b*16 + l15]
-        if (p.ep_params != nullptr) {  // inference: BatchNorm scale / shift (+ ReLU) on the fp32 accumulators
+        if (!RED && p.ep_params != nullptr) {  // inference: BatchNorm scale / shift (+ ReLU) on the fp32 accumulators
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const f32x4 s4 = *(const f32x4*)(p.ep_params + 2 * p.Cn + cobase + a * 16);
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
                 }
             }
         }
-        if (p.stats != nullptr) {
+        if (!RED && p.stats != nullptr) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const f32x4 sh = p.stat_shift != nullptr ? *(const f32x4*)(p.stat_shift + cobase + a * 16)
@@ -136,14 +143,36 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
             }
         }
         constexpr int OPITCH = BCO * 2 + 16;
-        constexpr int PPR = BCO / 8;
+        bf16x8 ry[NIT];
+        unsigned rb[NIT];
+        // (opaque copies: everything the folded reduction addresses is recomputed per tile -- hoisted out of the tile
+        // loop as invariants, its pointers were 15-20 registers the K loop had to carry, i.e. spills)
+        int rc8 = rc8_, rr0 = rr0_;
+        int l15e = l15, lge = lg;
+        asm volatile("" : "+v"(rc8), "+v"(rr0), "+v"(l15e), "+v"(lge));
+        const unsigned e0 = (unsigned)((m0 + rr0) * p.Cn + co0 + rc8 * 8);
+        if (RED) {  // what the folded reduction reads beside the tile: issued here, used after the tile is staged
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = m0 + rr0 + it * RSTEP;
+                ry[it] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                rb[it] = 0u;
+                if (row < p.M) {  // (scalar base + 32-bit offset: out and red_y share the element offset e)
+                    const unsigned e = e0 + (unsigned)(it * RSTEP * p.Cn);
+                    ry[it] = *(const bf16x8*)((const char*)p.red_y + e * 2u);
+                    rb[it] = p.red_bits != nullptr ? *(p.red_bits + (e >> 3)) : 0x100u;  // (0x100: a row that counts, no bits yet)
+                }
+            }
+        }
         __syncthreads();  // every wave has finished reading the operand tiles
         const bf16* addsrc = p.ep_res != nullptr ? p.ep_res : (p.accumulate ? p.out : nullptr);
         if (addsrc != nullptr) {
-            for (int i = tid; i < BM * PPR; i += 256) {
-                const int r = i / PPR, c8 = i - r * PPR;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {  // all of a thread's pieces in flight at once
+                const int r = rr0 + it * RSTEP;
                 if (m0 + r < p.M)
-                    *(bf16x8*)(smem + r * OPITCH + c8 * 16) = *(const bf16x8*)(addsrc + (size_t)(m0 + r) * p.Cn + co0 + c8 * 8);
+                    *(bf16x8*)(smem + r * OPITCH + rc8 * 16) =
+                        *(const bf16x8*)((const char*)addsrc + (e0 + (unsigned)(it * RSTEP * p.Cn)) * 2u);
             }
             __syncthreads();
         }
@@ -151,7 +180,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
         for (int b = 0; b < 4; ++b) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                bf16x4* q = (bf16x4*)(smem + (wm * 64 + b * 16 + l15) * OPITCH + (wco * 64 + a * 16 + lg * 4) * 2);
+                bf16x4* q = (bf16x4*)(smem + (wm * 64 + b * 16 + l15e) * OPITCH + (wco * 64 + a * 16 + lge * 4) * 2);
                 f32x4 v = acc[a][b];
                 if (addsrc != nullptr) {
                     const bf16x4 old = *q;
@@ -166,15 +195,75 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
             }
         }
         __syncthreads();
-        for (int i = tid; i < BM * PPR; i += 256) {
-            const int r = i / PPR, c8 = i - r * PPR;
-            if (m0 + r < p.M)
-                *(bf16x8*)(p.out + (size_t)(m0 + r) * p.Cn + co0 + c8 * 8) = *(const bf16x8*)(smem + r * OPITCH + c8 * 16);
+        if (RED) {
+            // the copy-out with the BatchNorm backward sums of the rows it writes: the ROUNDED values, as the separate
+            // reduction (chan_reduce_kernel<1, 3>) would read them back, in its access pattern -- a thread owns eight
+            // channels and every RSTEP-th row, y and the bits come in as whole 128-byte pieces (fetched above)
+            float rmean[8], rinv[8];  // (per tile, from the L1: sixteen registers the K loop does not have to carry)
+#pragma unroll
+            for (int k4 = 0; k4 < 2; ++k4) {
+                const f32x4 m4 = *(const f32x4*)(p.red_params + co0 + rc8 * 8 + k4 * 4);
+                const f32x4 i4 = *(const f32x4*)(p.red_params + p.Cn + co0 + rc8 * 8 + k4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rmean[k4 * 4 + j] = m4[j], rinv[k4 * 4 + j] = i4[j];
+            }
+            if (p.red_bits == nullptr) {  // mask mode 2: the ReLU mask is scale * y + shift > 0, the forward's expression
+                float rscale[8], rshift[8];
+#pragma unroll
+                for (int k4 = 0; k4 < 2; ++k4) {
+                    const f32x4 s4 = *(const f32x4*)(p.red_params + 2 * p.Cn + co0 + rc8 * 8 + k4 * 4);
+                    const f32x4 h4 = *(const f32x4*)(p.red_params + 3 * p.Cn + co0 + rc8 * 8 + k4 * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rscale[k4 * 4 + j] = s4[j], rshift[k4 * 4 + j] = h4[j];
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    unsigned mb = 0u;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) mb |= (bf2f(ry[it][k]) * rscale[k] + rshift[k]) > 0.f ? 1u << k : 0u;
+                    rb[it] = rb[it] != 0u ? mb : 0u;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int r = rr0 + it * RSTEP;
+                const bf16x8 piece = *(const bf16x8*)(smem + r * OPITCH + rc8 * 16);
+                if (m0 + r < p.M) *(bf16x8*)((char*)p.out + (e0 + (unsigned)(it * RSTEP * p.Cn)) * 2u) = piece;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float gk = ((rb[it] >> k) & 1u) ? bf2f(piece[k]) : 0.f;  // rows beyond M: no bits
+                    ra0[k] += gk;
+                    ra1[k] += gk * (bf2f(ry[it][k]) - rmean[k]) * rinv[k];
+                }
+            }
+        } else {
+            for (int i = tid; i < BM * PPR; i += 256) {
+                const int r = i / PPR, c8 = i - r * PPR;
+                if (m0 + r < p.M)
+                    *(bf16x8*)(p.out + (size_t)(m0 + r) * p.Cn + co0 + c8 * 8) = *(const bf16x8*)(smem + r * OPITCH + c8 * 16);
+            }
         }
         __syncthreads();  // the staged tile has been read out before the next tile's operands land on it
     }
 
-    if (p.stats != nullptr) {
+    float* const sums = RED ? p.red_sums : p.stats;
+    if (RED) {
+        float* sm = (float*)smem;  // [256][17]: chan_reduce_kernel's block reduction over the row lanes
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sm[tid * 17 + k] = ra0[k];
+            sm[tid * 17 + 8 + k] = ra1[k];
+        }
+        __syncthreads();
+        if (tid < 16 * PPR) {
+            const int gg = tid % PPR, k = tid / PPR;
+            float v = 0.f;
+#pragma unroll 8
+            for (int rr = 0; rr < RSTEP; ++rr) v += sm[(rr * PPR + gg) * 17 + k];
+            float* srep = sums + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
+            atomicAdd(srep + (k < 8 ? 0 : p.Cn) + co0 + gg * 8 + (k & 7), v);
+        }
+    } else if (sums != nullptr) {
         float* sred = (float*)smem;  // [WM][2][BCO]
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -193,7 +282,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
             }
         }
         __syncthreads();
-        float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
+        float* srep = sums + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
         for (int i = tid; i < 2 * BCO; i += 256) {
             const int mom = i / BCO, c = i - mom * BCO;
             float v = 0.f;
@@ -207,7 +296,9 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
     // blockIdx.y; bn_fin.h explains the memory-ordering side).  The tail is one round of loads whatever Cn is -- the
     // whole-layer form (one workgroup, Cn / 256 dependent rounds) cost a 2048-channel layer 11 us -- and it needs few
     // registers: unrolled over channels it had set this kernel's allocation at 248 VGPRs, i.e. its occupancy.
-    if (p.fin.ticket == nullptr || p.stats == nullptr) return;
+    // (the backward sums of the folded reduction finalize the same way: coef, dgamma, dbeta instead of the parameters)
+    unsigned* const ticket = RED ? p.red_fin.ticket : (p.stats != nullptr ? p.fin.ticket : nullptr);
+    if (ticket == nullptr) return;
     // (the flag lives in the dynamic LDS block: a static __shared__ word on top of 2 x 40 KB of operand buffers would
     // put the 64 x 256 form past the 80 KB it asks for)
     volatile unsigned* s_last_p = (volatile unsigned*)(smem + 8192);
@@ -215,9 +306,9 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
     __syncthreads();  // also: every thread is done with the reduction scratch at the head of smem
     if (tid == 0) {
         unsigned last = 0u;
-        const unsigned t = __hip_atomic_fetch_add(p.fin.ticket + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(ticket + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1u) {
-            __hip_atomic_store(p.fin.ticket + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ticket + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = 1u;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -232,10 +323,22 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
         float v = 0.f;
 #pragma unroll
         for (int r = 0; r < VC_STAT_REPLICAS; ++r)
-            v += vc_stat_load<true>(p.stats + (size_t)r * 2 * p.Cn + mom * p.Cn + c);
+            v += vc_stat_load<true>(sums + (size_t)r * 2 * p.Cn + mom * p.Cn + c);
         sfin[tid] = v;
     }
     __syncthreads();
+    if (RED) {
+        if (tid < BCO) {  // vc_bn_bwd_finalize_channel's arithmetic
+            const VcBnBwdFin& f = p.red_fin;
+            const int c = co0 + tid;
+            const float s = sfin[tid], q = sfin[BCO + tid];
+            f.coef[c] = s / f.count;
+            f.coef[p.Cn + c] = q / f.count;
+            if (f.dgamma != nullptr) f.dgamma[c] += q;
+            if (f.dbeta != nullptr) f.dbeta[c] += s;
+        }
+        return;
+    }
     if (tid < BCO) {
         const VcBnFin& f = p.fin;
         const int c = co0 + tid, C = p.Cn;
@@ -258,7 +361,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
     }
 }
 
-template <int BCO, int BM, int WPE>
+template <int BCO, int BM, int WPE, bool RED>
 int launch_pw(const VcPwParams& p, hipStream_t stream) {
     using Cfg = PwCfg<BCO, BM>;
     const bool one_chunk = p.K == 64;
@@ -276,11 +379,11 @@ int launch_pw(const VcPwParams& p, hipStream_t stream) {
     if (lds > 64 * 1024) {
         static VcPerDeviceOnce once;
         once.run([&] {
-            (void)hipFuncSetAttribute((const void*)pw_kernel<BCO, BM, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_2);
+            (void)hipFuncSetAttribute((const void*)pw_kernel<BCO, BM, WPE, RED>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_2);
         });
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((pw_kernel<BCO, BM, WPE>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((pw_kernel<BCO, BM, WPE, RED>), grid, dim3(256), lds, stream, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         vc_set_error("pointwise conv launch failed: %s", hipGetErrorString(e));
@@ -297,6 +400,13 @@ int vc_launch_pw(const VcPwParams& p, hipStream_t stream) {
         vc_set_error("pointwise conv: channels must be multiples of 64 (Cn=%d K=%d)", p.Cn, p.K);
         return -2;
     }
-    if (p.Cn % 128 == 0) return launch_pw<128, 128, VC_PW_WPE>(p, stream);
-    return launch_pw<64, 256, VC_PW_WPE>(p, stream);
+    if (p.red_sums != nullptr && (p.stats != nullptr || p.ep_params != nullptr || p.red_y == nullptr || p.red_params == nullptr)) {
+        vc_set_error("pointwise conv: the folded BatchNorm backward reduction needs y and params and excludes "
+                     "forward statistics and the inference epilogue");
+        return -2;
+    }
+    if (p.red_sums != nullptr)
+        return p.Cn % 128 == 0 ? launch_pw<128, 128, VC_PW_WPE, true>(p, stream) : launch_pw<64, 256, VC_PW_WPE, true>(p, stream);
+    if (p.Cn % 128 == 0) return launch_pw<128, 128, VC_PW_WPE, false>(p, stream);
+    return launch_pw<64, 256, VC_PW_WPE, false>(p, stream);
 }

@@ -22,6 +22,9 @@ F32 = torch.float32
 FUSED_EVAL_ACT = os.environ.get("VC_NO_EVAL_ACT") is None  # inference: BatchNorm + ReLU in the conv epilogue
 FUSED_BN_FIN = os.environ.get("VC_NO_BN_FIN") is None  # BatchNorm finalize done by the last workgroup of the producer
 SIDE_WGRAD = os.environ.get("VC_WGRAD_SIDE_STREAM", "1") != "0"  # weight gradients on a side stream (engine._wgrad)
+# the BatchNorm backward reduction of a block's last BN rides along with the data-gradient launch that completes the
+# gradient it reduces (vc_conv3d_dgrad_bnred; VC_NO_BNRED_FOLD=1 in the library runs the two launches instead)
+FOLD_BN_RED = os.environ.get("VC_NO_BNRED") is None
 RELU_BITS = os.environ.get("VC_NO_RELU_BITS") is None  # residual blocks save their ReLU mask as bits (VC_NO_RELU_BITS=1: read the activation instead)
 FIRST_STATS = os.environ.get("VC_FIRST_STATS") is not None  # stand-alone row-0-shifted statistics on a layer's first step
 
@@ -477,17 +480,30 @@ class R3DEngine:
         N, To, Ho, Wo, Cf = shape
         g = ops.gavgpool_bwd(dfeat.contiguous(), N, To * Ho * Wo, Cf, shape)
         self._t("final", dfeat=dfeat, dx=g)
-        for (cbs, ds), (xin, recs, dsrec) in zip(reversed(self.blocks), reversed(saved["blocks"])):
+        order = list(zip(reversed(self.blocks), reversed(saved["blocks"])))
+        coef = None  # of this block's last BN, when its reduction came with the dgrad that completed g
+        for bi, ((cbs, ds), (xin, recs, dsrec)) in enumerate(order):
             # last conv of the block: BN + residual + ReLU
             cb = cbs[-1]
             d, h, y, prm, out = recs[-1]  # `out`: the block output, or its ReLU mask as bits
             dy, gres = ops.bn_bwd(y, g, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias),
                                   mask=3 if out.dtype == torch.uint8 else 1, aux=out, want_g=True,
-                                  sums=sums_pool.take(cb.Co), ticket=self._bticket(cb))
+                                  sums=sums_pool.take(cb.Co) if coef is None else None, ticket=self._bticket(cb),
+                                  coef=coef, reduced=coef is not None)
+            coef = None
             self._ready(cb.bn.weight, cb.bn.bias)
             self._wgrad(d, h, dy, cb.conv)
             _, wd = cb.weights()
-            dz = ops.conv3d_dgrad(d, dy, wd)
+            fold = FOLD_BN_RED and FUSED_BN_FIN and self.trace is None
+
+            def red_of(pcb, py, pprm, bits):
+                """the reduction of pcb's BatchNorm backward, to ride along with the dgrad that makes its gradient"""
+                c = torch.empty(2, pcb.Co, dtype=F32, device=dev)
+                return c, (py, pprm, bits, sums_pool.take(pcb.Co), self._ticket(pcb, True), c,
+                           self.gview(pcb.bn.weight), self.gview(pcb.bn.bias))
+
+            icoef, red = red_of(cbs[-2], recs[-2][2], recs[-2][3], None) if fold else (None, None)
+            dz = ops.conv3d_dgrad(d, dy, wd, bnred=red)
             self._t(cb.name, dz=g, dy=dy, gres=gres, dx=dz, dx_base=None)
             del dy
             # middle / first convs: BN + ReLU
@@ -497,7 +513,9 @@ class R3DEngine:
                 # BN -> ReLU with nothing in between: the ReLU mask is recomputed from y (scale * y + shift > 0,
                 # the forward's own expression) instead of reading the activation z a third tensor per pass
                 dy, _ = ops.bn_bwd(y, dz, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias), mask=2,
-                                   sums=sums_pool.take(cb.Co), ticket=self._bticket(cb))
+                                   sums=sums_pool.take(cb.Co) if icoef is None else None, ticket=self._bticket(cb),
+                                   coef=icoef, reduced=icoef is not None)
+                icoef = None
                 self._ready(cb.bn.weight, cb.bn.bias)
                 if i == 0 and ds is not None:
                     # downsample branch first so the first conv's dgrad can accumulate onto it
@@ -517,10 +535,18 @@ class R3DEngine:
                 dz_in = dz
                 if i == 0:
                     base = gres.clone() if self.trace is not None else None
-                    dz = ops.conv3d_dgrad(d, dy, wd, out=gres, accumulate=True)
+                    red = None
+                    if fold and bi + 1 < len(order):
+                        # dz is the gradient the previous block's last BN reduces next: take its sums here
+                        (pcbs, _), (_, precs, _) = order[bi + 1]
+                        _, _, py, pprm, pout = precs[-1]
+                        if pout.dtype == torch.uint8:
+                            coef, red = red_of(pcbs[-1], py, pprm, pout)
+                    dz = ops.conv3d_dgrad(d, dy, wd, out=gres, accumulate=True, bnred=red)
                 else:
                     base = None
-                    dz = ops.conv3d_dgrad(d, dy, wd)
+                    icoef, red = red_of(cbs[i - 1], recs[i - 1][2], recs[i - 1][3], None) if fold else (None, None)
+                    dz = ops.conv3d_dgrad(d, dy, wd, bnred=red)
                 self._t(cb.name, dz=dz_in, dy=dy, dx=dz, dx_base=base)
                 del dy
             g = dz

@@ -156,7 +156,10 @@ def conv3d_fwd(d, x, wf, stats=None, out=None, fin=None, act_params=None, relu=T
     return out
 
 
-def conv3d_dgrad(d, dy, wd, out=None, accumulate=False):
+def conv3d_dgrad(d, dy, wd, out=None, accumulate=False, bnred=None):
+    """bnred = (y, params, relu_bits, sums, ticket, coef, dgamma, dbeta): vc_conv3d_dgrad_bnred -- the reduction of the
+    BatchNorm backward that consumes dx (mask mode 3, or 2 when relu_bits is None) comes with the conv (dense
+    geometries: from its epilogue); follow it with bn_bwd(..., coef=coef, reduced=True)."""
     To, Ho, Wo = d.out_dims()
     taps = d.kt * d.kh * d.kw
     _chk(dy, BF16, d.N * To * Ho * Wo * d.Co, "dy")
@@ -168,8 +171,23 @@ def conv3d_dgrad(d, dy, wd, out=None, accumulate=False):
     _chk(out, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "dx")
     ev = TIMER.begin(_conv_key("dgrad", d), _conv_flops(d)) if TIMER is not None else None
     ws, wsb = _workspace(d, 1, dy.device)
-    check(lib.vc_conv3d_dgrad(d, ptr(dy), ptr(wd), ptr(out), 1 if accumulate else 0, ws, wsb, cur_stream()),
-          "vc_conv3d_dgrad")
+    if bnred is not None:
+        ry, rp, rb, rs, rt, rc, rdg, rdb = bnred
+        n = d.N * d.Ti * d.Hi * d.Wi * d.Ci
+        _chk(ry, BF16, n, "bnred y")
+        _chk(rp, F32, 4 * d.Ci, "bnred params")
+        _chk(rb, torch.uint8, n // 8, "bnred relu bits")
+        _chk(rs, F32, VC_STAT_REPLICAS * 2 * d.Ci, "bnred sums")
+        _chk(rt, torch.int32, capi.VC_TICKET_WORDS, "bnred ticket")
+        _chk(rc, F32, 2 * d.Ci, "bnred coef")
+        _chk(rdg, F32, d.Ci, "bnred dgamma")
+        _chk(rdb, F32, d.Ci, "bnred dbeta")
+        red = capi.BnBwdRed(ptr(ry), ptr(rp), ptr(rb), ptr(rs), ptr(rt), ptr(rc), ptr(rdg), ptr(rdb))
+        check(lib.vc_conv3d_dgrad_bnred(d, ptr(dy), ptr(wd), ptr(out), 1 if accumulate else 0, red, ws, wsb,
+                                        cur_stream()), "vc_conv3d_dgrad_bnred")
+    else:
+        check(lib.vc_conv3d_dgrad(d, ptr(dy), ptr(wd), ptr(out), 1 if accumulate else 0, ws, wsb, cur_stream()),
+              "vc_conv3d_dgrad")
     if ev is not None:
         ev.record()
     return out
@@ -399,9 +417,10 @@ def bn_apply(y, params, C, residual=None, relu=True, out=None, relu_bits=None):
 
 
 def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=False, sums=None, coef=None,
-           dy=None, g_out=None, ticket=None):
+           dy=None, g_out=None, ticket=None, reduced=False):
     """BatchNorm backward (batch statistics).  Returns (dy, g) with g = masked dz or None.
-    `ticket` (capi.VC_TICKET_WORDS zero int32 words): the reduction's last workgroup does the finalize (one launch less)."""
+    `ticket` (capi.VC_TICKET_WORDS zero int32 words): the reduction's last workgroup does the finalize (one launch less).
+    `reduced`: coef, dgamma and dbeta are already there (conv3d_dgrad's bnred made them with dz); only the apply pass runs."""
     n = y.numel()
     _chk(y, BF16, name="y")
     _chk(dz, BF16, n, "dz")
@@ -413,7 +432,10 @@ def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=Fal
     _chk(gamma_grad, F32, C, "dgamma")
     _chk(beta_grad, F32, C, "dbeta")
     rows = n // C
-    if sums is None:
+    if reduced:
+        if coef is None:
+            raise capi.Vc3dError("bn_bwd: reduced=True needs the coef the reduction produced")
+    elif sums is None:
         sums = new_stats(C, y.device)
     _chk(sums, F32, VC_STAT_REPLICAS * 2 * C, "sums")
     if coef is None:
@@ -426,7 +448,9 @@ def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=Fal
         g_out = torch.empty_like(y)
     _chk(g_out, BF16, n, "g_out")
     s = cur_stream()
-    if ticket is not None:
+    if reduced:
+        pass
+    elif ticket is not None:
         _chk(ticket, torch.int32, capi.VC_TICKET_WORDS, "ticket")
         check(lib.vc_bn_bwd_reduce_fin(ptr(y), ptr(dz), ptr(aux), ptr(params), ptr(sums), rows, C, mask, ptr(ticket),
                                        ptr(coef), ptr(gamma_grad), ptr(beta_grad), s), "vc_bn_bwd_reduce_fin")
