@@ -439,12 +439,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 stage(tap, cch, fa0, fb0, fa1, fb1);
                 stage(tap + 1, cch, fa1, fb1, fa0, fb0);
             }
-            if (tap + 1 < p.ntaps) {
-                stage(tap, cch, fa0, fb0, fa1, fb1);
-                mfma_all(fa1, fb1);
-            } else {
-                mfma_all(fa0, fb0);
-            }
+            mfma_all(fa0, fb0);  // (odd tap count, see below)
         } else {
             static_assert(NB == 4 || KS == 1, "the in-place fragment refresh is written for one k-step per tap");
             bf16x8 fa0[KS][4], fa1[KS][4], fb[KS][NB];
@@ -454,12 +449,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 stage2(tap, cch, fa0, fa1, fb);
                 stage2(tap + 1, cch, fa1, fa0, fb);
             }
-            if (tap + 1 < p.ntaps) {
-                stage2(tap, cch, fa0, fa1, fb);
-                mfma_all(fa1, fb);
-            } else {
-                mfma_all(fa0, fb);
-            }
+            // ntaps is odd (checked by the host; every axis of a "same"-padded 1- or 3-wide kernel has 1 or 3 live
+            // taps), so the last tap's fragments are in fa0.  With the even-count tail as a second path, the
+            // accumulators met in phi nodes at its merge that the register allocator did not coalesce: this form
+            // spilled ~100 VGPRs, stores and reloads between the MFMAs, and the 64 x 64 forms sat at 250-256.
+            mfma_all(fa0, fb);
         }
         VC_STAMP(cch == cbeg ? 4 : 6);
     }
@@ -641,13 +635,14 @@ static const double vc_halo_kpad = getenv("VC_HALO_KPAD") ? atof(getenv("VC_HALO
 
 int vc_halo_plan(int NP, int T, int H, int W, int Cs, int Cn, int ntaps, VcHaloPlan* plan) {
     const int HW = H * W;
+    if ((ntaps & 1) == 0) return -1;  // the kernel's tap pipeline is written for an odd count (what halo convs have)
     const char* env = getenv("VC_HALO_FORCE");  // "NW,TT,SEG,splits[,CK[,pad[,NB]]]" for experiments
     static const bool no_pad = getenv("VC_HALO_NO_PAD") != nullptr;
-    // Measured on MI355X (layer1, 64 x 8x28x28 x 64 -> 64, scripts/halo_stamps.py): the two-workgroup form runs its tap
-    // steps at 1100 clocks per 28 MFMAs x 2 workgroups (83 % of the shared pipe) but LDS-DMA of 64-byte rows moves
-    // 4-6 B/clk/CU against 11 for 128-byte rows, so fill + epilogue grow from 19k to 54k clocks per tile and the
-    // kernel ties the one-workgroup form (0.129 ms both).  Kept for experiments: VC_HALO_2WG=1 lets the planner pick it.
-    static const bool no_2wg = getenv("VC_HALO_2WG") == nullptr;
+    // The two-workgroups-per-CU form (4 waves of 64 x 112, 32-channel chunks): one workgroup's image fill, barriers and
+    // epilogue run beside the other's MFMAs.  Measured on MI355X, layer1 (64 x 8x28x28 x 64 -> 64): forward 0.131 ->
+    // 0.110 ms, dgrad 0.126 -> 0.117; layer2 (128 ch, 4x14x14) stays with the eight-wave form (0.056 against 0.064).
+    // VC_HALO_NO_2WG=1 takes it out of the planner.
+    static const bool no_2wg = getenv("VC_HALO_NO_2WG") != nullptr;
     static const double k2wg = getenv("VC_HALO_K2WG") ? atof(getenv("VC_HALO_K2WG")) : 1.15;
     double best = 1e30;
     VcHaloPlan bp;
@@ -663,9 +658,7 @@ int vc_halo_plan(int NP, int T, int H, int W, int Cs, int Cn, int ntaps, VcHaloP
         const int nchunks = Cs / CK;
         const int PR = CK == 32 ? 16 : 8;
         for (int pad = 0; pad <= (no_pad ? 0 : 1); ++pad) {
-            // the 32-channel forms exist in the padded variant only (fewer instantiations to keep within the register
-            // budget; the padded 64 x 112 form itself spills ~100 VGPRs at the 256 it may use, which is part of why it
-            // only ties with the eight-wave form: it stays opt-in)
+            // the 32-channel forms exist in the padded variant only (the masked variants spilled 100+ registers)
             if (CK == 32 && !pad) continue;
             const int BM = NW * NB * 16;
             for (int SEG = 1; SEG <= (HW < BM ? HW : BM); ++SEG) {
@@ -737,7 +730,7 @@ extern "C" void vc_debug_halo_stamps(long long* buf) { g_halo_dbg = buf; }  // t
 
 int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream) {
     p.dbg = g_halo_dbg;
-    if (p.Cs % 64 != 0 || p.Cn % 64 != 0 || p.ntaps < 1 || p.ntaps > 32) {
+    if (p.Cs % 64 != 0 || p.Cn % 64 != 0 || p.ntaps < 1 || p.ntaps > 32 || (p.ntaps & 1) == 0) {
         vc_set_error("halo conv: bad channels/taps (Cs=%d Cn=%d taps=%d)", p.Cs, p.Cn, p.ntaps);
         return -2;
     }
