@@ -52,6 +52,7 @@ __device__ __attribute__((aligned(128))) unsigned int vc_halo_zero_page[32];
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15), result in every lane: full-rate VALU, no LDS
 __device__ __forceinline__ float row16_sum(float v) {
@@ -63,7 +64,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 #ifndef VC_HALO_ABLATE
-#define VC_HALO_ABLATE 0  // timing experiments only (scripts/halo_ablate.sh): 1 no tap barrier, 2 no image reads, 4 no weight reads, 8 no weight DMA, 16 no MFMA
+#define VC_HALO_ABLATE 0  // timing experiments only (scripts/halo_ablate.sh): 1 no tap barrier, 2 no image reads, 4 no weight reads, 8 no weight DMA, 16 no MFMA, 64 / 128 image fill from the zero page with / without its address arithmetic (padded form)
 #endif
 
 // PAD: the LDS image is stored zero-padded -- (R + 2) x (W + 1) + 1 rows per plane, out-of-sample rows filled
@@ -99,8 +100,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int lg = lane >> 4;
 
     // ---- tile coordinates
-    const int tg = blockIdx.x / p.nseg;
-    const int sg = blockIdx.x - tg * p.nseg;
+    // Workgroups are dealt round-robin to the 8 XCDs (workgroup id mod 8), each with its own L2.  Neighbouring tiles
+    // share their halos (two of a tile's TT + 2 planes with each temporal neighbour, two of its R + 2 rows with each
+    // segment neighbour: the image is 2-3x the tile), so XCD k takes the k-th contiguous eighth of the tiles and the
+    // shared rows are L2 hits there instead of fabric traffic into eight L2s.
+    unsigned bx = blockIdx.x;
+    if (p.xcd_map) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const int tg = (int)bx / p.nseg;
+    const int sg = (int)bx - tg * p.nseg;
     const int P0 = tg * p.TT;          // first (n,t) plane of the tile
     const int s0 = sg * p.SEG;         // first (h,w) row of the tile inside a plane
     const int co0 = blockIdx.y * 64;
@@ -189,6 +196,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     }
 
+    const int nchunks = p.Cs / CK;
+    int cbeg = 0, cend = nchunks;
+    if (p.splits > 1) {
+        cbeg = blockIdx.z * p.cps;
+        cend = min(nchunks, cbeg + p.cps);
+    }
+
     // ---- loader roles
     // weight tile: 8 pieces of 8 rows x 128 B; wave w issues pieces w, w+NW, ...
     const int prow = lane / Cfg::SLOTS;   // row inside a piece
@@ -212,23 +226,74 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             // image row r = q*HR + hh*(W+1) + ww, HR = (R+2)*(W+1) + 1  ->  plane P0-1+q, row h0-1+hh, column ww-1; zero
             // outside.  ONE zero column per h-row: column 0 is the left neighbour of w = 0 and, being the element after
             // the previous row's w = W-1, that row's right neighbour too; the plane's last row gets one trailing element.
+            //
+            // Addressing: a row's source is a 32-bit offset from a tile base held in SGPRs, its validity four range tests
+            // against tile-uniform bounds, and the rows that stay zero are not loaded from a zero page: their lanes are
+            // masked off the DMA and the rows are zeroed by plain LDS stores, once per tile (no chunk ever writes them).
+            // (What bounds the fill is the CU's LDS-DMA rate, ~14 B/clk with all of its waves issuing: cheaper address
+            // arithmetic, an XCD-aware tile order and a VGPR-staged fill -- 60 % slower -- all left its 9-11k clocks
+            // per 67-134 KB where they were; scripts/halo_ablate.sh, modes 64 / 128.)
             const int p0t = P0 - (int)vc_div((unsigned)P0, p.dT) * p.T;
             const int h0 = sg * p.R;
-            for (int pc = wave; pc < p.npieces; pc += NW) {
-                const int r = pc * PR + prow;
-                const int q = (int)vc_div((unsigned)r, p.dHR);
-                const int u = r - q * p.HR;
-                const int hh = (int)vc_div((unsigned)u, p.dWp);
-                const int w = u - hh * p.Wp - 1;
-                const int h = h0 - 1 + hh;
-                const int P = P0 - 1 + q;
-                // hh == R + 2: the one trailing element of a plane (the right neighbour of its last row's last column)
-                const bool ok = r < p.halo_rows && (q >= 1 || p0t != 0) && (q <= p.TT || p0t + p.TT != p.T) && P < p.NP &&
-                                hh < p.R + 2 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-                const long grow = (long)P * HW + h * p.W + w;
+            const int q_lo = p0t == 0 ? 1 : 0;  // planes of the image that exist: [q_lo, q_hi)
+            const int q_hi = min(p.TT + 2 - (p0t + p.TT == p.T ? 1 : 0), p.NP - P0 + 1);
+            const int h_lo = h0 > 0 ? 0 : 1;    // h-rows: [h_lo, h_hi)
+            const int h_hi = min(p.R + 2, p.H - h0 + 1);
+            const long long base_e = ((long long)(P0 - 1) * HW + (long long)(h0 - 1) * p.W - 1) * p.Cs + cch * CK;
+            const char* const tbase = (const char*)p.src + base_e * 2;  // uniform; may lie before the tensor (never read there)
+            // A wave takes a contiguous run of pieces, so (plane q, h-row hh, column wc) of its row advance by PR rows per
+            // piece with at most one wrap each (PR <= Wp; narrower images divide per piece): no division, and the one
+            // multiply left (row offset x Cs) is a 24-bit one.
+            const int ppw = (p.npieces + NW - 1) / NW;
+            int pc = wave * ppw;
+            const int pc_end = min(pc + ppw, p.npieces);
+            int r = pc * PR + prow;
+            int q = (int)vc_div((unsigned)r, p.dHR);
+            int u = r - q * p.HR;
+            int hh = (int)vc_div((unsigned)u, p.dWp);
+            int wc = u - hh * p.Wp;  // image column: 0 is the zero column, 1 + w the tensor's column w
+            int qHW = q * HW;
+            int rowoff = qHW + hh * p.W + wc;  // global row of (q, hh, wc) relative to the tile base
+            const bool stepwise = PR <= p.Wp;
+            const unsigned nq = (unsigned)(q_hi - q_lo), nh = (unsigned)(h_hi - h_lo);
+            auto step = [&](bool& ok, unsigned& rel) {  // this piece's row: loadable?, byte offset from tbase; then advance
+                ok = r < p.halo_rows && (unsigned)(q - q_lo) < nq && (unsigned)(hh - h_lo) < nh && wc >= 1;
                 const int ls = pslot ^ Cfg::swz(r);
-                const gptr_t src = ok ? (gptr_t)(p.src + (grow * p.Cs + cch * CK + ls * 8)) : zero;
-                __builtin_amdgcn_global_load_lds(src, (lptr_t)(dst + pc * 1024), 16, 0, 0);
+                rel = (__umul24((unsigned)rowoff, (unsigned)p.Cs) + (unsigned)(ls * 8)) * 2u;
+                r += PR;
+                if (stepwise) {
+                    u += PR, wc += PR, rowoff += PR;
+                    const bool hwrap = wc >= p.Wp;  // next h-row: the zero column is not in the tensor, one row less
+                    wc = hwrap ? wc - p.Wp : wc;
+                    hh = hwrap ? hh + 1 : hh;
+                    rowoff = hwrap ? rowoff - 1 : rowoff;
+                    const bool pwrap = u >= p.HR;   // next plane: u < PR <= Wp, so h-row 0, column u
+                    u = pwrap ? u - p.HR : u;
+                    qHW = pwrap ? qHW + HW : qHW;
+                    q = pwrap ? q + 1 : q;
+                    hh = pwrap ? 0 : hh;
+                    wc = pwrap ? u : wc;
+                    rowoff = pwrap ? qHW + u : rowoff;
+                } else {
+                    q = (int)vc_div((unsigned)r, p.dHR);
+                    u = r - q * p.HR;
+                    hh = (int)vc_div((unsigned)u, p.dWp);
+                    wc = u - hh * p.Wp;
+                    rowoff = q * HW + hh * p.W + wc;
+                }
+            };
+            for (; pc < pc_end; ++pc) {
+                bool ok;
+                unsigned rel;
+                step(ok, rel);
+                if (VC_HALO_ABLATE & 128) {
+                    __builtin_amdgcn_global_load_lds(zero, (lptr_t)(dst + pc * 1024), 16, 0, 0);
+                } else if (ok) {
+                    const gptr_t src = (VC_HALO_ABLATE & 64) ? zero : (gptr_t)(tbase + rel);
+                    __builtin_amdgcn_global_load_lds(src, (lptr_t)(dst + pc * 1024), 16, 0, 0);
+                } else if (cch == cbeg) {
+                    *(u32x4*)(dst + pc * 1024 + lane * 16) = (u32x4){0u, 0u, 0u, 0u};
+                }
             }
         } else {
             // image row r = q*HR + u  ->  global row gplane0 + q*HW + u
@@ -258,12 +323,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     VC_STAMP(1);
 
-    const int nchunks = p.Cs / CK;
-    int cbeg = 0, cend = nchunks;
-    if (p.splits > 1) {
-        cbeg = blockIdx.z * p.cps;
-        cend = min(nchunks, cbeg + p.cps);
-    }
     const int aswz = Cfg::swz(l15);  // == swz(a*16 + l15)
     const unsigned halo_base = HALO_OFF;
 
@@ -611,6 +670,7 @@ int launch_halo(const VcHaloParams& p, hipStream_t stream) {
     static VcPerDeviceOnce once;  // thread-safe, once per device
     once.run([&]() { (void)hipFuncSetAttribute((const void*)halo_conv_kernel<NW, CK, PAD, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     dim3 grid(p.ntg * p.nseg, p.Cn / 64, p.splits > 1 ? p.splits : 1);
+
     (void)hipGetLastError();
     hipLaunchKernelGGL((halo_conv_kernel<NW, CK, PAD, NB>), grid, dim3(NW * 64), lds, stream, p);
     const hipError_t e = hipGetLastError();
@@ -760,6 +820,8 @@ int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream) 
     }
     p.ntg = (p.NP + p.TT - 1) / p.TT;
     p.nseg = (HW + p.SEG - 1) / p.SEG;
+    static const bool no_xcd_map = getenv("VC_NO_XCD_MAP") != nullptr;
+    p.xcd_map = ((p.ntg * p.nseg) % 8 == 0 && p.ntg * p.nseg >= 16 && !no_xcd_map) ? 1 : 0;
     if (p.TT * p.SEG > plan.NW * plan.NB * 16 || halo_lds(plan.NW, plan.CK, p.npieces, plan.NB) > 160 * 1024 ||
         (plan.CK != 32 && plan.CK != 64) || (plan.CK == 32 && plan.NW != 4) ||
         !(plan.NB == 4 || (plan.CK == 32 && plan.NB == 7))) {

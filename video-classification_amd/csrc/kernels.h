@@ -106,6 +106,7 @@ struct VcHaloParams {
     float* partial;
     long long partial_stride;
     long long* dbg;   // nullable: 8 s_memtime stamps per workgroup (tuning aid)
+    int xcd_map;      // set by the launcher: blockIdx.x -> tile so that each XCD works on a contiguous range of tiles
     VcTap taps[32];   // ot/oh/ow in [-1,1]; src_off is rewritten to the row shift inside the LDS image
 };
 struct VcHaloPlan {
@@ -126,6 +127,7 @@ struct VcWgrad9Params {
     int NP, T, H, W, Cs, Co, Kw;
     int rows_per_split, splits;
     int dt0, ndt;    // temporal offsets computed: dt = dt0 - 1 .. dt0 + ndt - 2 (all three, or only dt = 0 when T == 1)
+    int xcd_map;     // set by the launcher: workgroup id -> (slice, co, dt/ci) so that a slice's workgroups share an XCD
     long long* dbg;  // nullable: per-workgroup phase clocks (tuning aid)
     VcFastDiv dHW, dT, dW;
 };

@@ -62,9 +62,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nci = p.Cs >> 6;
-    const int dtg = p.dt0 + blockIdx.x / nci;  // 0..2  -> dt = dtg - 1
-    const int cic = blockIdx.x % nci;
-    const int coc = blockIdx.y;
+    // Workgroups go round-robin to the 8 XCDs (linear id mod 8), each with its own L2, and the workgroups of one slice
+    // of m -- three dt offsets, the ci and co chunks -- read the same dY rows and overlapping image rows: XCD k takes
+    // the k-th contiguous share of the (z, y, x) order, so that a slice's workgroups meet in one L2.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_map) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
+        const unsigned k = lin & 7u, base = total >> 3, rem = total & 7u;
+        const unsigned logical = k * base + (k < rem ? k : rem) + (lin >> 3);
+        bx = logical % gridDim.x;
+        const unsigned t = logical / gridDim.x;
+        by = t % gridDim.y;
+        bz = t / gridDim.y;
+    }
+    const int dtg = p.dt0 + (int)bx / nci;  // 0..2  -> dt = dtg - 1
+    const int cic = (int)bx % nci;
+    const int coc = (int)by;
     const int HW = p.H * p.W;
     const int XR = CH + 2 * p.W + 2;            // image rows per chunk
     const int dt = dtg - 1;
@@ -77,7 +91,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     auto sT = [&](int b) { return (unsigned*)(smem + RS + b * Cfg::BUF + Cfg::ROWS * RS); };
     if (tid < RS / 4) ((unsigned*)zrow)[tid] = 0u;
 
-    const long mb = (long)blockIdx.z * p.rows_per_split;
+    const long mb = (long)bz * p.rows_per_split;
     const long mend = mb + p.rows_per_split < Mtot ? mb + p.rows_per_split : Mtot;
     const int nchunks = (int)((mend - mb + CH - 1) / CH);
 
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         VC_W9_LAP(3);
     }
     if (p.dbg != nullptr && tid == 0) {
-        long long* d = p.dbg + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+        long long* d = p.dbg + ((size_t)(bz * gridDim.y + by) * gridDim.x + bx) * 8;
         d[0] = tq[0], d[1] = tq[1], d[2] = tq[2], d[3] = tq[3], d[4] = t_prev - t_begin, d[5] = nchunks, d[6] = t_begin;
     }
 
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     int how = 1;  // 1: += (this workgroup owns the elements), 2: store into its slab, 0: atomics
     if (p.splits > 1) {
         if (p.partial != nullptr) {
-            dst = p.partial + (size_t)blockIdx.z * p.partial_stride;
+            dst = p.partial + (size_t)bz * p.partial_stride;
             how = 2;
         } else {
             how = 0;
@@ -359,6 +373,8 @@ static int launch_wgrad9(const VcWgrad9Params& p, hipStream_t stream) {
 }
 
 int vc_launch_wgrad9(VcWgrad9Params& p, hipStream_t stream) {
+    static const bool no_xcd_map = getenv("VC_NO_XCD_MAP") != nullptr;
+    p.xcd_map = no_xcd_map ? 0 : 1;
     p.dbg = g_w9_dbg;
     const bool four = wgrad9_four_waves(p.W) && p.rows_per_split % 64 == 0;
     if ((!four && wgrad9_lds<8>(p.W) == 0) || p.Cs % 64 != 0 || p.Co % 64 != 0) {
