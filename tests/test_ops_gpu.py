@@ -743,15 +743,17 @@ def test_pointwise_kernel_matches_general_kernel(geom):
 
 
 @pytest.mark.parametrize("geom", [(64, 64, 8, 28, 28, 256, 1), (4, 128, 4, 14, 14, 512, 1), (3, 256, 2, 7, 7, 1024, 1),
-                                  (2, 512, 1, 4, 4, 2048, 1), (1, 64, 1, 3, 5, 64, 1), (2, 64, 2, 9, 9, 64, 3)])
+                                  (2, 512, 1, 4, 4, 2048, 1), (1, 64, 1, 3, 5, 64, 1), (2, 64, 2, 9, 9, 64, 3),
+                                  (8, 64, 8, 28, 28, 64, 3), (6, 128, 4, 14, 14, 128, 3), (16, 256, 2, 7, 7, 256, 3),
+                                  (3, 128, 3, 10, 6, 64, 3)])
 @pytest.mark.parametrize("accumulate,use_bits", [(False, True), (True, True), (False, False)])
 def test_dgrad_with_folded_bn_backward_reduction(geom, accumulate, use_bits):
     """vc_conv3d_dgrad_bnred (dense geometries: the BatchNorm backward sums of the tensor the data-gradient GEMM
     completes are taken in its epilogue, pw_conv.hip) against the two launches it replaces, vc_conv3d_dgrad +
     vc_bn_bwd_reduce_fin with the ReLU bits (mask mode 3) or with the mask recomputed from y (mode 2, no residual): the
     same dx bit for bit, and coef / dgamma / dbeta equal to the order of the float additions (both reduce the ROUNDED
-    dx).  `geom` = the conv (Co -> its input Ci = the BatchNorm's channels); the last one is a 3x3x3 conv, which the
-    entry point runs as the two launches itself."""
+    dx).  `geom` = the conv (Co -> its input Ci = the BatchNorm's channels).  The 3x3x3 ones take the halo kernel
+    (plain and split-K plans): the entry point runs them as the two launches itself."""
     _need_gpu()
     from vc3d import ops
     N, Co, T, H, W, Ci, k = geom

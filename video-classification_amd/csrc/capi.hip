@@ -467,6 +467,8 @@ static int conv3d_dgrad_impl(const vc_conv3d_desc* d, const void* dy, const void
         }
         return 0;
     }
+    // (3x3x3 stride-1: the halo kernel.  Folding the reduction into its copy-out as well measured no gain -- its
+    // epilogue is exposed, and the extra y reads cost it what the separate pass costs -- so `red` runs as a launch there.)
     if (halo_ok(d)) return halo_run(d, true, dy, w_dgrad, dx, nullptr, nullptr, nullptr, 0, nullptr, accumulate, workspace, ws_bytes, stream);
     const int ntaps_all = d->kt * d->kh * d->kw;
     const size_t dx_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci;

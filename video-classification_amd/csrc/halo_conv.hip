@@ -546,6 +546,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
         }
     }
+    if (p.accumulate) {
+        // dx += : the old values are added to the fp32 accumulators (one rounding), each wave on its own before the
+        // barrier -- the loads' latency falls into the time the other waves still spend in their tap loops
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (ooff[b] < 0) continue;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const bf16x4 old = *(const bf16x4*)(p.out + (size_t)ooff[b] + cobase + a * 16);
+                acc[a][b][0] += bf2f(old[0]), acc[a][b][1] += bf2f(old[1]);
+                acc[a][b][2] += bf2f(old[2]), acc[a][b][3] += bf2f(old[3]);
+            }
+        }
+    }
     __syncthreads();  // every wave has left the tap loop: the image area is free
     // The image area is reused: [NW][WS positions][64 co] bf16 with a 144-byte row pitch for the output
     // tile (so that it leaves as whole 128-byte channels-last rows, 16 bytes per lane), then
@@ -554,16 +568,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     char* otile = smem + HALO_OFF + wave * WS * OPITCH;
     float* sstat = (float*)(smem + HALO_OFF + NW * WS * OPITCH);
     int* sooff = (int*)(sstat + NW * 128);  // [NW][WS] output offsets of the wave's slots
-    if (!p.accumulate) {
+    // Every path stages the tile in LDS and leaves as whole rows; sooff = the rows' output offsets.
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < NB; ++b)
+        if (lg == 0) sooff[wave * WS + b * 16 + l15] = ooff[b];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const f32x4 v = acc[a][b];
-                *(bf16x4*)(otile + (b * 16 + l15) * OPITCH + (a * 16 + lg * 4) * 2) =
-                    (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-            }
-            if (lg == 0) sooff[wave * WS + b * 16 + l15] = ooff[b];
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bf16x4* q = (bf16x4*)(otile + (b * 16 + l15) * OPITCH + (a * 16 + lg * 4) * 2);
+            const f32x4 v = acc[a][b];
+            *q = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         }
     }
     if (p.stats != nullptr) {
@@ -613,7 +628,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
         atomicAdd(srep + (tid < 64 ? 0 : p.Cn) + co0 + (tid & 63), s);
     }
-    if (!p.accumulate) {
+    {
         // each wave streams its own WS x 64 tile: 8 rows of 128 bytes per instruction
 #pragma unroll
         for (int i = 0; i < NB * 2; ++i) {
@@ -633,22 +648,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                 }
                 *(bf16x8*)(p.out + (size_t)oo + co0 + (lane & 7) * 8) = v;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (ooff[b] < 0) continue;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                bf16* dst = p.out + (size_t)ooff[b] + cobase + a * 16;
-                f32x4 v = acc[a][b];
-                const bf16x4 old = *(const bf16x4*)dst;
-                v[0] += bf2f(old[0]);
-                v[1] += bf2f(old[1]);
-                v[2] += bf2f(old[2]);
-                v[3] += bf2f(old[3]);
-                *(bf16x4*)dst = (bf16x4){f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
             }
         }
     }
