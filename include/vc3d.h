@@ -107,14 +107,23 @@ int vc_conv3d_fwd_noalloc(const vc_conv3d_desc* d, const void* x, const void* w,
 int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx,
                     int accumulate /* dx += instead of dx = */, void* workspace, size_t ws_bytes,
                     void* stream);
-/* vc_conv3d_dgrad followed by the reduction of the BatchNorm backward that consumes dx.  When dx is the gradient that
- * reaches `relu(bn(y))` (backbone.py:50-55,88-95) or `relu(bn(y) + residual)` (backbone.py:56-61,97-102: the block's
- * first conv hands it to the previous block), the next thing the backward does is vc_bn_bwd_reduce_fin(y, dx,
- * relu_bits, params, sums, rows, C = Ci, mask, ticket, coef, dgamma, dbeta) -- a pass that reads dx back.  This entry
- * point produces the same sums, coef, dgamma += and dbeta += with the conv: dense (1x1x1, unit stride, unsplit)
- * geometries take them in the GEMM's epilogue from the tile they are about to write, any other geometry runs the
- * two launches.  relu_bits given: mask mode 3; null: mask mode 2 (the mask is recomputed from y).  sums must be zero
- * on entry; accumulate as in vc_conv3d_dgrad (the sums are over the accumulated dx). */
+/* vc_conv3d_dgrad with the two elementwise neighbours of a residual block's data gradient folded in (both optional):
+ *
+ * red -- the reduction of the BatchNorm backward that consumes dx.  When dx is the gradient that reaches `relu(bn(y))`
+ * (backbone.py:50-55,88-95) or `relu(bn(y) + residual)` (backbone.py:56-61,97-102: the block's first conv hands it to
+ * the previous block), the next thing the backward does is vc_bn_bwd_reduce_fin(y, dx, relu_bits, params, sums, rows,
+ * C = Ci, mask, ticket, coef, dgamma, dbeta) -- a pass that reads dx back.  This entry point produces the same sums,
+ * coef, dgamma += and dbeta += with the conv.  relu_bits given: mask mode 3; null: mask mode 2 (the mask is recomputed
+ * from y).  sums must be zero on entry; with accumulate the sums are over the accumulated dx.
+ *
+ * acc_relu_bits (with accumulate = 1) -- dx holds the gradient g that reached the block's `relu(... + residual)`, and
+ * what has to be added to the conv's data gradient is the part of it that passes that ReLU into the identity shortcut
+ * (backbone.py:59-61,100-102): dx = (dx where its bit of acc_relu_bits is set, else 0) + dgrad.  The masked copy of g
+ * that vc_bn_bwd_apply would write (g_out) and this call would read back is never made.
+ *
+ * Dense geometries (1x1x1, unit stride, unsplit) take both in the GEMM's own launch -- the mask where the old dx tile
+ * is staged, the sums from the finished tile in the epilogue; any other geometry runs them as separate launches
+ * inside this call (same results). */
 typedef struct {
     const void* y;            /* what the BatchNorm normalised: [N*Ti*Hi*Wi][Ci] bf16 */
     const float* params;      /* [4][Ci] of that BatchNorm */
@@ -125,8 +134,9 @@ typedef struct {
     float* dgamma;            /* += nullable */
     float* dbeta;             /* += nullable */
 } vc_bn_bwd_red;
-int vc_conv3d_dgrad_bnred(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
-                          const vc_bn_bwd_red* red, void* workspace, size_t ws_bytes, void* stream);
+int vc_conv3d_dgrad_fused(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                          const uint8_t* acc_relu_bits /* nullable */, const vc_bn_bwd_red* red /* nullable */,
+                          void* workspace, size_t ws_bytes, void* stream);
 int vc_conv3d_wgrad(const vc_conv3d_desc* d, const void* x, const void* dy,
                     float* dw /* fp32 [Co][kt][kh][kw][Ci], += */, void* workspace, size_t ws_bytes,
                     void* stream);

@@ -746,14 +746,16 @@ def test_pointwise_kernel_matches_general_kernel(geom):
                                   (2, 512, 1, 4, 4, 2048, 1), (1, 64, 1, 3, 5, 64, 1), (2, 64, 2, 9, 9, 64, 3),
                                   (8, 64, 8, 28, 28, 64, 3), (6, 128, 4, 14, 14, 128, 3), (16, 256, 2, 7, 7, 256, 3),
                                   (3, 128, 3, 10, 6, 64, 3)])
-@pytest.mark.parametrize("accumulate,use_bits", [(False, True), (True, True), (False, False)])
+@pytest.mark.parametrize("accumulate,use_bits", [(False, True), (True, True), (False, False), ("masked", True)])
 def test_dgrad_with_folded_bn_backward_reduction(geom, accumulate, use_bits):
-    """vc_conv3d_dgrad_bnred (dense geometries: the BatchNorm backward sums of the tensor the data-gradient GEMM
+    """vc_conv3d_dgrad_fused's reduction (dense geometries: the BatchNorm backward sums of the tensor the data-gradient GEMM
     completes are taken in its epilogue, pw_conv.hip) against the two launches it replaces, vc_conv3d_dgrad +
     vc_bn_bwd_reduce_fin with the ReLU bits (mask mode 3) or with the mask recomputed from y (mode 2, no residual): the
     same dx bit for bit, and coef / dgamma / dbeta equal to the order of the float additions (both reduce the ROUNDED
     dx).  `geom` = the conv (Co -> its input Ci = the BatchNorm's channels).  The 3x3x3 ones take the halo kernel
-    (plain and split-K plans): the entry point runs them as the two launches itself."""
+    (plain and split-K plans): the entry point runs them as the two launches itself.  accumulate == "masked": the
+    existing dx counts only where its own ReLU bit is set (acc_relu_bits: the identity shortcut's gradient), against
+    masking it first with torch."""
     _need_gpu()
     from vc3d import ops
     N, Co, T, H, W, Ci, k = geom
@@ -775,18 +777,26 @@ def test_dgrad_with_folded_bn_backward_reduction(geom, accumulate, use_bits):
         ops.bn_apply(y, params, Ci, residual=res, relu=True, relu_bits=bits)
     mask = 3 if use_bits else 2
 
+    acc_bits = None
+    if accumulate == "masked":
+        keep = torch.rand(M * Ci, generator=g).view(-1, 8) > 0.4
+        acc_bits = (keep.to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8).cuda()
+        masked_base = torch.where(keep.view(base.shape).cuda(), base, torch.zeros_like(base))
+
     def run(folded):
         dx = base.clone() if accumulate else torch.empty_like(base)
+        if acc_bits is not None and not folded:
+            dx = masked_base.clone()
         dgamma, dbeta = torch.full((Ci,), 0.25, device="cuda"), torch.full((Ci,), -0.5, device="cuda")  # += targets
         coef = torch.empty(2, Ci, device="cuda")
         ticket = torch.zeros(64, dtype=torch.int32, device="cuda")
         sums = ops.new_stats(Ci, "cuda")
         if folded:
-            ops.conv3d_dgrad(d, dy, wd, out=dx, accumulate=accumulate,
+            ops.conv3d_dgrad(d, dy, wd, out=dx, accumulate=bool(accumulate), acc_bits=acc_bits,
                              bnred=(y, params, bits, sums, ticket, coef, dgamma, dbeta))
             dyb, gm = ops.bn_bwd(y, dx, params, Ci, dgamma, dbeta, mask=mask, aux=bits, want_g=True, coef=coef, reduced=True)
         else:
-            ops.conv3d_dgrad(d, dy, wd, out=dx, accumulate=accumulate)
+            ops.conv3d_dgrad(d, dy, wd, out=dx, accumulate=bool(accumulate))
             dyb, gm = ops.bn_bwd(y, dx, params, Ci, dgamma, dbeta, mask=mask, aux=bits, want_g=True, sums=sums, coef=coef,
                                  ticket=ticket)
         torch.cuda.synchronize()

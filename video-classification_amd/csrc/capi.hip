@@ -447,10 +447,26 @@ extern "C" {
 static inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 static inline int posmod(int a, int b) { return ((a % b) + b) % b; }
 
-// red (nullable): the BatchNorm backward reduction over dx that the caller wants with it (vc_conv3d_dgrad_bnred);
-// *folded tells whether the conv's own launch has taken it.
+// The data gradient goes out as one dense GEMM launch of pw_conv.hip (1x1x1, unit stride, unsplit, one batch): the
+// route on which vc_conv3d_dgrad_fused's extras ride along.
+static bool dgrad_dense_route(const vc_conv3d_desc* d, const void* workspace, size_t ws_bytes) {
+    int To, Ho, Wo;
+    if (conv_dims(d, To, Ho, Wo)) return false;
+    if (conv_max_batch(d, To, Ho, Wo) < d->N) return false;
+    if (d->kt * d->kh * d->kw != 1 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt != 0 || d->ph != 0 || d->pw != 0)
+        return false;
+    const size_t dx_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
+    const int splits = dgrad_splits(d);
+    if (splits > 1 && workspace != nullptr && ws_bytes >= (size_t)splits * dx_e * 4) return false;
+    return getenv("VC_NO_PW_KERNEL") == nullptr && getenv("VC_NO_POINTWISE") == nullptr && getenv("VC_NO_BNRED_FOLD") == nullptr;
+}
+
+// vc_conv3d_dgrad_fused's extras -- red (nullable): the BatchNorm backward reduction over dx that the caller wants with
+// it; acc_bits (nullable, with accumulate): ReLU bits the old dx is masked by before the sum.  *folded tells whether the
+// conv's own launch has taken them (both or neither).
 static int conv3d_dgrad_impl(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
-                             const vc_bn_bwd_red* red, bool* folded, void* workspace, size_t ws_bytes, void* stream) {
+                             const uint8_t* acc_bits, const vc_bn_bwd_red* red, bool* folded, void* workspace,
+                             size_t ws_bytes, void* stream) {
     int To, Ho, Wo;
     int rc = conv_check(d, To, Ho, Wo);
     if (rc) return rc;
@@ -462,7 +478,7 @@ static int conv3d_dgrad_impl(const vc_conv3d_desc* d, const void* dy, const void
             vc_conv3d_desc sub = *d;
             sub.N = d->N - n0 < nb ? d->N - n0 : nb;
             rc = conv3d_dgrad_impl(&sub, (const bf16*)dy + n0 * out_s, w_dgrad, (bf16*)dx + n0 * in_s, accumulate, nullptr,
-                                   nullptr, workspace, ws_bytes, stream);
+                                   nullptr, nullptr, workspace, ws_bytes, stream);
             if (rc) return rc;
         }
         return 0;
@@ -474,15 +490,16 @@ static int conv3d_dgrad_impl(const vc_conv3d_desc* d, const void* dy, const void
     const size_t dx_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
     int splits = dgrad_splits(d);
     if (splits > 1 && (workspace == nullptr || ws_bytes < (size_t)splits * dx_e * 4)) splits = 1;
-    if (red != nullptr && splits <= 1 && ntaps_all == 1 && d->st == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 &&
-        d->ph == 0 && d->pw == 0 && getenv("VC_NO_PW_KERNEL") == nullptr && getenv("VC_NO_POINTWISE") == nullptr &&
-        getenv("VC_NO_BNRED_FOLD") == nullptr) {
+    if ((red != nullptr || acc_bits != nullptr) && dgrad_dense_route(d, workspace, ws_bytes)) {
         // a dense GEMM whose epilogue holds the finished dx tile: the reduction rides along (pw_conv.hip)
         VcPwParams w = {};
         w.src = (const bf16*)dy, w.wgt = (const bf16*)w_dgrad, w.out = (bf16*)dx;
         w.M = (int)(dx_e / d->Ci), w.K = d->Co, w.Cn = d->Ci, w.accumulate = accumulate;
-        w.red_y = (const bf16*)red->y, w.red_params = red->params, w.red_bits = red->relu_bits, w.red_sums = red->sums;
-        w.red_fin = VcBnBwdFin{red->ticket, red->coef, red->dgamma, red->dbeta, (float)w.M};
+        w.acc_bits = accumulate ? acc_bits : nullptr;
+        if (red != nullptr) {
+            w.red_y = (const bf16*)red->y, w.red_params = red->params, w.red_bits = red->relu_bits, w.red_sums = red->sums;
+            w.red_fin = VcBnBwdFin{red->ticket, red->coef, red->dgamma, red->dbeta, (float)w.M};
+        }
         *folded = true;
         return vc_launch_pw(w, S(stream));
     }
@@ -596,18 +613,31 @@ static int conv3d_dgrad_impl(const vc_conv3d_desc* d, const void* dy, const void
 
 int vc_conv3d_dgrad(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
                     void* workspace, size_t ws_bytes, void* stream) {
-    return conv3d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, nullptr, workspace, ws_bytes, stream);
+    return conv3d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, nullptr, nullptr, workspace, ws_bytes, stream);
 }
 
-int vc_conv3d_dgrad_bnred(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
-                          const vc_bn_bwd_red* red, void* workspace, size_t ws_bytes, void* stream) {
-    VC_REQUIRE(d && red && red->y && red->params && red->sums && red->ticket && red->coef,
-               "conv3d_dgrad_bnred: y, params, sums, ticket and coef are required");
-    VC_REQUIRE(pow2_channels(d->Ci), "bn: C=%d must be a power of two in [64, 2048]", d->Ci);
-    bool folded = false;
-    const int rc = conv3d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, red, &folded, workspace, ws_bytes, stream);
-    if (rc || folded) return rc;
+int vc_conv3d_dgrad_fused(const vc_conv3d_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                          const uint8_t* acc_relu_bits, const vc_bn_bwd_red* red, void* workspace, size_t ws_bytes,
+                          void* stream) {
+    VC_REQUIRE(d, "conv3d_dgrad_fused: null descriptor");
+    VC_REQUIRE(acc_relu_bits == nullptr || accumulate, "conv3d_dgrad_fused: acc_relu_bits needs accumulate");
+    if (red != nullptr) {
+        VC_REQUIRE(red->y && red->params && red->sums && red->ticket && red->coef,
+                   "conv3d_dgrad_fused: y, params, sums, ticket and coef are required");
+        VC_REQUIRE(pow2_channels(d->Ci), "bn: C=%d must be a power of two in [64, 2048]", d->Ci);
+    }
     const int64_t rows = (int64_t)d->N * d->Ti * d->Hi * d->Wi;
+    bool folded = false;
+    int rc;
+    if (acc_relu_bits != nullptr && !dgrad_dense_route(d, workspace, ws_bytes)) {
+        // the general route: dx is masked in a pass of its own, then the plain accumulate (and the reduction after it)
+        VC_REQUIRE(dx, "conv3d_dgrad_fused: null dx");
+        rc = vc_ew_mask_bits(dx, acc_relu_bits, (long)(rows * d->Ci), S(stream));
+        if (rc) return rc;
+        acc_relu_bits = nullptr;
+    }
+    rc = conv3d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, acc_relu_bits, red, &folded, workspace, ws_bytes, stream);
+    if (rc || folded || red == nullptr) return rc;
     return vc_bn_bwd_reduce_fin(red->y, dx, red->relu_bits, red->params, red->sums, rows, d->Ci, red->relu_bits ? 3 : 2,
                                 red->ticket, red->coef, red->dgamma, red->dbeta, stream);
 }

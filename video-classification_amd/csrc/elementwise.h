@@ -36,6 +36,7 @@ int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void
 int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, int Ci, int taps,
                               unsigned live, hipStream_t s);
 int vc_ew_add(const void* a, const void* b, void* out, long n, hipStream_t s);
+int vc_ew_mask_bits(void* x, const uint8_t* bits, long n, hipStream_t s);
 int vc_ew_maxpool_fwd(const void* y, const float* params, void* out, uint8_t* idx, const VcPoolGeom& g, hipStream_t s);
 int vc_ew_maxpool_bwd(const void* dout, const uint8_t* idx, void* din, const VcPoolGeom& g, hipStream_t s);
 int vc_ew_avgpool_fwd(const void* in, float* out, int N, int S, int C, hipStream_t s);

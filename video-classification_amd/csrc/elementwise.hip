@@ -379,6 +379,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16x8* __restr
 }
 
 // ------------------------------------------------------------------ add (bf16): out = a + b
+// x = x where its ReLU bit is set, else 0 (one byte of bits per 16-byte piece): the general form of the masked
+// accumulate of vc_conv3d_dgrad_fused, for geometries whose conv kernel does not apply the mask itself
+__global__ __launch_bounds__(256) void mask_bits_kernel(bf16x8* __restrict__ x, const uint8_t* __restrict__ bits, long n8) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        bf16x8 v = x[i];
+        const unsigned mb = bits[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = ((mb >> k) & 1u) ? v[k] : (bf16)0;
+        x[i] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(const bf16x8* __restrict__ a, const bf16x8* __restrict__ b,
                                                   bf16x8* __restrict__ out, long n8) {
     const long stride = (long)gridDim.x * blockDim.x;
@@ -1491,6 +1504,11 @@ int vc_ew_bn_bwd_apply(const void* y, const void* dz, const void* aux, const flo
         else VC_BWD_APPLY(2, false);
     }
 #undef VC_BWD_APPLY
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_mask_bits(void* x, const uint8_t* bits, long n, hipStream_t s) {
+    const long n8 = n / 8;
+    VC_LAUNCH(mask_bits_kernel, dim3(grid_for(n8)), dim3(256), 0, s, (bf16x8*)x, bits, n8);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_add(const void* a, const void* b, void* out, long n, hipStream_t s) {

@@ -54,6 +54,7 @@ struct VcPwParams {
     const bf16* ep_res;
     int M, K, Cn;
     int accumulate;
+    const uint8_t* acc_bits;  // nullable (with accumulate): ReLU bits of out's elements; the old value counts where its bit is set
     // The reduction of a BatchNorm backward folded into the (data-gradient) launch that completes its incoming
     // gradient: out is the gradient reaching `relu(bn(red_y) [+ residual])`; the epilogue adds sum g and sum g * xhat
     // over its tile (g = out where the ReLU passed, xhat = (red_y - mean) * invstd) to red_sums -- what

@@ -66,16 +66,19 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * BM;
+        unsigned woff_t = woff;  // (opaque per tile: hoisted out of the tile loop, the pieces' 64-bit addresses were spills)
+        int lrow_t = lrow;
+        asm volatile("" : "+v"(woff_t), "+v"(lrow_t));
         auto issue_chunk = [&](int c, int buf) {
             char* bW = smem + buf * Cfg::BUF_BYTES + wave * (8 * ROWB);
             char* bX = bW + BCO * ROWB;
 #pragma unroll
             for (int j = 0; j < Cfg::NW; ++j)
-                __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (woff + (unsigned)(j * 32 * p.K + c * 64) * 2u)),
+                __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (woff_t + (unsigned)(j * 32 * p.K + c * 64) * 2u)),
                                                  (lptr_t)(bW + j * 32 * ROWB), 16, 0, 0);
 #pragma unroll
             for (int i = 0; i < Cfg::NX; ++i) {
-                const int m = m0 + i * 32 + lrow;
+                const int m = m0 + i * 32 + lrow_t;
                 const unsigned off = (unsigned)(m * p.K + lslot * 8 + c * 64) * 2u;
                 const gptr_t src = m < p.M ? (gptr_t)(xbase + off) : zero;
                 __builtin_amdgcn_global_load_lds(src, (lptr_t)(bX + i * 32 * ROWB), 16, 0, 0);
@@ -151,7 +154,27 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
         int l15e = l15, lge = lg;
         asm volatile("" : "+v"(rc8), "+v"(rr0), "+v"(l15e), "+v"(lge));
         const unsigned e0 = (unsigned)((m0 + rr0) * p.Cn + co0 + rc8 * 8);
-        if (RED) {  // what the folded reduction reads beside the tile: issued here, used after the tile is staged
+        __syncthreads();  // every wave has finished reading the operand tiles
+        const bf16* addsrc = p.ep_res != nullptr ? p.ep_res : (p.accumulate ? p.out : nullptr);
+        if (addsrc != nullptr) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {  // a thread's pieces in flight at once (RED: in two halves, for its registers)
+                if (RED && it == NIT / 2) asm volatile("" ::: "memory");
+                const int r = rr0 + it * RSTEP;
+                if (m0 + r < p.M) {
+                    const unsigned e = e0 + (unsigned)(it * RSTEP * p.Cn);
+                    bf16x8 piece = *(const bf16x8*)((const char*)addsrc + e * 2u);
+                    if (p.acc_bits != nullptr) {  // dx = relu_mask(dx) + ...: the eight channels of a piece share one byte of bits
+                        const unsigned mb = p.acc_bits[e >> 3];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) piece[k] = ((mb >> k) & 1u) ? piece[k] : (bf16)0;
+                    }
+                    *(bf16x8*)(smem + r * OPITCH + rc8 * 16) = piece;
+                }
+            }
+        }
+        if (RED) {  // what the folded reduction reads beside the tile: issued here (after the old tile's pieces have gone
+                    // through their registers), used after the tile is staged
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int row = m0 + rr0 + it * RSTEP;
@@ -164,18 +187,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
                 }
             }
         }
-        __syncthreads();  // every wave has finished reading the operand tiles
-        const bf16* addsrc = p.ep_res != nullptr ? p.ep_res : (p.accumulate ? p.out : nullptr);
-        if (addsrc != nullptr) {
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {  // all of a thread's pieces in flight at once
-                const int r = rr0 + it * RSTEP;
-                if (m0 + r < p.M)
-                    *(bf16x8*)(smem + r * OPITCH + rc8 * 16) =
-                        *(const bf16x8*)((const char*)addsrc + (e0 + (unsigned)(it * RSTEP * p.Cn)) * 2u);
-            }
-            __syncthreads();
-        }
+        if (addsrc != nullptr) __syncthreads();
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
 #pragma unroll
@@ -246,17 +258,19 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
         __syncthreads();  // the staged tile has been read out before the next tile's operands land on it
     }
 
+    // (the thread id again, from the lane count: carried through the tile loop in a register, it was one more spill)
+    const int tid_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) + wave * 64;
     float* const sums = RED ? p.red_sums : p.stats;
     if (RED) {
         float* sm = (float*)smem;  // [256][17]: chan_reduce_kernel's block reduction over the row lanes
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            sm[tid * 17 + k] = ra0[k];
-            sm[tid * 17 + 8 + k] = ra1[k];
+            sm[tid_e * 17 + k] = ra0[k];
+            sm[tid_e * 17 + 8 + k] = ra1[k];
         }
         __syncthreads();
-        if (tid < 16 * PPR) {
-            const int gg = tid % PPR, k = tid / PPR;
+        if (tid_e < 16 * PPR) {
+            const int gg = tid_e % PPR, k = tid_e / PPR;
             float v = 0.f;
 #pragma unroll 8
             for (int rr = 0; rr < RSTEP; ++rr) v += sm[(rr * PPR + gg) * 17 + k];
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
         }
         __syncthreads();
         float* srep = sums + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
-        for (int i = tid; i < 2 * BCO; i += 256) {
+        for (int i = tid_e; i < 2 * BCO; i += 256) {
             const int mom = i / BCO, c = i - mom * BCO;
             float v = 0.f;
 #pragma unroll
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
     volatile unsigned* s_last_p = (volatile unsigned*)(smem + 8192);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's atomics have been performed
     __syncthreads();  // also: every thread is done with the reduction scratch at the head of smem
-    if (tid == 0) {
+    if (tid_e == 0) {
         unsigned last = 0u;
         const unsigned t = __hip_atomic_fetch_add(ticket + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1u) {
@@ -318,20 +332,20 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
     __syncthreads();
     if (*s_last_p == 0u) return;
     float* sfin = (float*)smem;  // [2][BCO]: sum and sum of squares over the replicas, in replica order
-    if (tid < 2 * BCO) {
-        const int mom = tid / BCO, c = co0 + (tid - mom * BCO);
+    if (tid_e < 2 * BCO) {
+        const int mom = tid_e / BCO, c = co0 + (tid_e - mom * BCO);
         float v = 0.f;
 #pragma unroll
         for (int r = 0; r < VC_STAT_REPLICAS; ++r)
             v += vc_stat_load<true>(sums + (size_t)r * 2 * p.Cn + mom * p.Cn + c);
-        sfin[tid] = v;
+        sfin[tid_e] = v;
     }
     __syncthreads();
     if (RED) {
-        if (tid < BCO) {  // vc_bn_bwd_finalize_channel's arithmetic
+        if (tid_e < BCO) {  // vc_bn_bwd_finalize_channel's arithmetic
             const VcBnBwdFin& f = p.red_fin;
-            const int c = co0 + tid;
-            const float s = sfin[tid], q = sfin[BCO + tid];
+            const int c = co0 + tid_e;
+            const float s = sfin[tid_e], q = sfin[BCO + tid_e];
             f.coef[c] = s / f.count;
             f.coef[p.Cn + c] = q / f.count;
             if (f.dgamma != nullptr) f.dgamma[c] += q;
@@ -339,12 +353,12 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
         }
         return;
     }
-    if (tid < BCO) {
+    if (tid_e < BCO) {
         const VcBnFin& f = p.fin;
-        const int c = co0 + tid, C = p.Cn;
-        const float m1 = sfin[tid] / f.count;
+        const int c = co0 + tid_e, C = p.Cn;
+        const float m1 = sfin[tid_e] / f.count;
         const float mean = (f.shift != nullptr ? f.shift[c] : 0.f) + m1;
-        float var = sfin[BCO + tid] / f.count - m1 * m1;
+        float var = sfin[BCO + tid_e] / f.count - m1 * m1;
         var = var > 0.f ? var : 0.f;
         if (f.shift_out != nullptr) f.shift_out[c] = mean;
         const float invstd = rsqrtf(var + f.eps);

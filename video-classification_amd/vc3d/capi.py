@@ -56,7 +56,7 @@ _I = C.c_int32
 _L = C.c_int64
 _F = C.c_float
 class BnBwdRed(C.Structure):
-    """vc_bn_bwd_red: the BatchNorm backward reduction that rides along with vc_conv3d_dgrad_bnred (include/vc3d.h)."""
+    """vc_bn_bwd_red: the BatchNorm backward reduction that rides along with vc_conv3d_dgrad_fused (include/vc3d.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("y", "params", "relu_bits", "sums", "ticket", "coef", "dgamma", "dbeta")]
 
 
@@ -77,7 +77,7 @@ PROTOTYPES = {
     "vc_static_scratch_bytes": [],
     "vc_conv3d_fwd_noalloc": [_CD, _P, _P, _P, _P, _P],
     "vc_conv3d_dgrad": [_CD, _P, _P, _P, _I, _P, C.c_size_t, _P],
-    "vc_conv3d_dgrad_bnred": [_CD, _P, _P, _P, _I, C.POINTER(BnBwdRed), _P, C.c_size_t, _P],
+    "vc_conv3d_dgrad_fused": [_CD, _P, _P, _P, _I, _P, C.POINTER(BnBwdRed), _P, C.c_size_t, _P],
     "vc_conv3d_wgrad": [_CD, _P, _P, _P, _P, C.c_size_t, _P],
     "vc_pack_weight": [_P, _P, _P, _I, _I, _I, _P],
     "vc_sgd_step": [_P, _P, _P, _P, _L, _F, _F, _F, _I, _P],

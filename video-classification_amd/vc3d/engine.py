@@ -23,7 +23,7 @@ FUSED_EVAL_ACT = os.environ.get("VC_NO_EVAL_ACT") is None  # inference: BatchNor
 FUSED_BN_FIN = os.environ.get("VC_NO_BN_FIN") is None  # BatchNorm finalize done by the last workgroup of the producer
 SIDE_WGRAD = os.environ.get("VC_WGRAD_SIDE_STREAM", "1") != "0"  # weight gradients on a side stream (engine._wgrad)
 # the BatchNorm backward reduction of a block's last BN rides along with the data-gradient launch that completes the
-# gradient it reduces (vc_conv3d_dgrad_bnred; VC_NO_BNRED_FOLD=1 in the library runs the two launches instead)
+# gradient it reduces (vc_conv3d_dgrad_fused; VC_NO_BNRED_FOLD=1 in the library runs the two launches instead)
 FOLD_BN_RED = os.environ.get("VC_NO_BNRED") is None
 RELU_BITS = os.environ.get("VC_NO_RELU_BITS") is None  # residual blocks save their ReLU mask as bits (VC_NO_RELU_BITS=1: read the activation instead)
 FIRST_STATS = os.environ.get("VC_FIRST_STATS") is not None  # stand-alone row-0-shifted statistics on a layer's first step
@@ -486,8 +486,13 @@ class R3DEngine:
             # last conv of the block: BN + residual + ReLU
             cb = cbs[-1]
             d, h, y, prm, out = recs[-1]  # `out`: the block output, or its ReLU mask as bits
+            # identity shortcut into a pointwise first conv: the masked copy of g (gres) is not made -- that conv's data
+            # gradient accumulates onto g itself and applies the ReLU bits to it on the way (vc_conv3d_dgrad_fused)
+            d0 = recs[0][0]
+            masked_acc = (FOLD_BN_RED and self.trace is None and ds is None and out.dtype == torch.uint8 and
+                          d0.kt * d0.kh * d0.kw == 1 and d0.st * d0.sh * d0.sw == 1)
             dy, gres = ops.bn_bwd(y, g, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias),
-                                  mask=3 if out.dtype == torch.uint8 else 1, aux=out, want_g=True,
+                                  mask=3 if out.dtype == torch.uint8 else 1, aux=out, want_g=not masked_acc,
                                   sums=sums_pool.take(cb.Co) if coef is None else None, ticket=self._bticket(cb),
                                   coef=coef, reduced=coef is not None)
             coef = None
@@ -542,7 +547,10 @@ class R3DEngine:
                         _, _, py, pprm, pout = precs[-1]
                         if pout.dtype == torch.uint8:
                             coef, red = red_of(pcbs[-1], py, pprm, pout)
-                    dz = ops.conv3d_dgrad(d, dy, wd, out=gres, accumulate=True, bnred=red)
+                    if masked_acc:
+                        dz = ops.conv3d_dgrad(d, dy, wd, out=g, accumulate=True, bnred=red, acc_bits=out)
+                    else:
+                        dz = ops.conv3d_dgrad(d, dy, wd, out=gres, accumulate=True, bnred=red)
                 else:
                     base = None
                     icoef, red = red_of(cbs[i - 1], recs[i - 1][2], recs[i - 1][3], None) if fold else (None, None)

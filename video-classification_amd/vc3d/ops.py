@@ -156,10 +156,11 @@ def conv3d_fwd(d, x, wf, stats=None, out=None, fin=None, act_params=None, relu=T
     return out
 
 
-def conv3d_dgrad(d, dy, wd, out=None, accumulate=False, bnred=None):
-    """bnred = (y, params, relu_bits, sums, ticket, coef, dgamma, dbeta): vc_conv3d_dgrad_bnred -- the reduction of the
-    BatchNorm backward that consumes dx (mask mode 3, or 2 when relu_bits is None) comes with the conv (dense
-    geometries: from its epilogue); follow it with bn_bwd(..., coef=coef, reduced=True)."""
+def conv3d_dgrad(d, dy, wd, out=None, accumulate=False, bnred=None, acc_bits=None):
+    """vc_conv3d_dgrad_fused's extras.  bnred = (y, params, relu_bits, sums, ticket, coef, dgamma, dbeta): the reduction
+    of the BatchNorm backward that consumes dx (mask mode 3, or 2 when relu_bits is None) comes with the conv (dense
+    geometries: from its epilogue); follow it with bn_bwd(..., coef=coef, reduced=True).  acc_bits (with accumulate):
+    the existing dx counts only where its ReLU bit is set."""
     To, Ho, Wo = d.out_dims()
     taps = d.kt * d.kh * d.kw
     _chk(dy, BF16, d.N * To * Ho * Wo * d.Co, "dy")
@@ -171,8 +172,11 @@ def conv3d_dgrad(d, dy, wd, out=None, accumulate=False, bnred=None):
     _chk(out, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "dx")
     ev = TIMER.begin(_conv_key("dgrad", d), _conv_flops(d)) if TIMER is not None else None
     ws, wsb = _workspace(d, 1, dy.device)
-    if bnred is not None:
-        ry, rp, rb, rs, rt, rc, rdg, rdb = bnred
+    if acc_bits is not None and not accumulate:
+        raise capi.Vc3dError("conv3d_dgrad: acc_bits needs accumulate")
+    _chk(acc_bits, torch.uint8, d.N * d.Ti * d.Hi * d.Wi * d.Ci // 8, "acc_bits")
+    if bnred is not None or acc_bits is not None:
+        ry, rp, rb, rs, rt, rc, rdg, rdb = bnred if bnred is not None else (None,) * 8
         n = d.N * d.Ti * d.Hi * d.Wi * d.Ci
         _chk(ry, BF16, n, "bnred y")
         _chk(rp, F32, 4 * d.Ci, "bnred params")
@@ -182,9 +186,10 @@ def conv3d_dgrad(d, dy, wd, out=None, accumulate=False, bnred=None):
         _chk(rc, F32, 2 * d.Ci, "bnred coef")
         _chk(rdg, F32, d.Ci, "bnred dgamma")
         _chk(rdb, F32, d.Ci, "bnred dbeta")
-        red = capi.BnBwdRed(ptr(ry), ptr(rp), ptr(rb), ptr(rs), ptr(rt), ptr(rc), ptr(rdg), ptr(rdb))
-        check(lib.vc_conv3d_dgrad_bnred(d, ptr(dy), ptr(wd), ptr(out), 1 if accumulate else 0, red, ws, wsb,
-                                        cur_stream()), "vc_conv3d_dgrad_bnred")
+        red = None if bnred is None else capi.BnBwdRed(ptr(ry), ptr(rp), ptr(rb), ptr(rs), ptr(rt), ptr(rc), ptr(rdg),
+                                                       ptr(rdb))
+        check(lib.vc_conv3d_dgrad_fused(d, ptr(dy), ptr(wd), ptr(out), 1 if accumulate else 0, ptr(acc_bits), red, ws, wsb,
+                                        cur_stream()), "vc_conv3d_dgrad_fused")
     else:
         check(lib.vc_conv3d_dgrad(d, ptr(dy), ptr(wd), ptr(out), 1 if accumulate else 0, ws, wsb, cur_stream()),
               "vc_conv3d_dgrad")
