@@ -103,6 +103,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16x8* __restrict_
 // sums[2][C].  The number of float atomics of a launch is RS x 2C whatever the channel split, so wide layers get
 // their parallelism from channel slices (C / 64 of them) and a small RS: with whole rows per block the 2-3 million
 // device-scope atomics of a C >= 512 layer took 90-120 us for a few MB of input (R3D-50 layer3/4).
+// y = (z - shift) / scale carries z's bf16 rounding, |z / gamma| * 2^-9 in xhat: fine unless |beta| > 16 |gamma| (or gamma == 0)
+__device__ __forceinline__ bool vc_pooled_z_ok(float mean, float invstd, float scale, float shift) {
+    const float beta = shift + mean * scale;  // scale = gamma * invstd
+    return scale != 0.f && fabsf(beta) * invstd <= 16.f * fabsf(scale);
+}
+
 template <int MODE, int MASK>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restrict__ y, const bf16x8* __restrict__ dz,
                                                           const bf16x8* __restrict__ aux,
@@ -140,6 +146,16 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restri
             shift[k] = params[3 * C + g * 8 + k];
         }
     }
+    // MASK 4: `y` holds z = relu(scale * y + shift) rounded to bf16 (the max pool's output at its arg-max) and y is
+    // solved from it, z > 0 being the ReLU mask; channels where that is ill-conditioned (vc_pooled_z_ok) add nothing
+    // here and are taken by bn_bwd_reduce_pooled_kernel's gather in a second launch.
+    float rscale[8];
+    unsigned zokm = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        rscale[k] = 0.f;
+        if (MASK == 4 && vc_pooled_z_ok(mean[k], invstd[k], scale[k], shift[k])) rscale[k] = 1.f / scale[k], zokm |= 1u << k;
+    }
     for (long row = (long)rs * 32 + r; row < rows; row += (long)RS * 32) {
         const long i = row * groups + g;
         float f[8];
@@ -162,6 +178,10 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restri
                 if (MASK == 1) gk = m[k] > 0.f ? gk : 0.f;
                 if (MASK == 2) gk = (f[k] * scale[k] + shift[k]) > 0.f ? gk : 0.f;
                 if (MASK == 3) gk = ((mb >> k) & 1u) ? gk : 0.f;
+                if (MASK == 4) {
+                    gk = (f[k] > 0.f && ((zokm >> k) & 1u)) ? gk : 0.f;
+                    f[k] = (f[k] - shift[k]) * rscale[k];
+                }
                 a0[k] += gk;
                 a1[k] += gk * (f[k] - mean[k]) * invstd[k];
             }
@@ -775,7 +795,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16* _
                                                                    const uint8_t* __restrict__ idx,
                                                                    const bf16x8* __restrict__ pooled,
                                                                    const float* __restrict__ params, float* sums,
-                                                                   VcPoolGeom g, VcBnBwdFin fin) {
+                                                                   VcPoolGeom g, VcBnBwdFin fin, int fixup) {
+    // fixup: the channels solved from z have been summed by chan_reduce_kernel<1, 4>; this launch adds the others
+    // (normally none: every thread skips its loop and its atomics) and runs the finalize
     __shared__ float sm[256 * 17];
     __shared__ int lut[256];  // tap -> input row offset from the window origin
     const int C = g.C, groups = C >> 3;
@@ -798,23 +820,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16* _
     float rscale[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const float beta = shift[k] + mean[k] * scale[k];  // scale = gamma * invstd
-        zok[k] = scale[k] != 0.f && fabsf(beta) * invstd[k] <= 16.f * fabsf(scale[k]);
+        zok[k] = vc_pooled_z_ok(mean[k], invstd[k], scale[k], shift[k]);
         all_z = all_z && zok[k];
         rscale[k] = zok[k] ? 1.f / scale[k] : 0.f;
     }
-    __syncthreads();
-    const long total = (long)g.N * g.To * g.Ho * g.Wo * groups;
+    const bool idle = __syncthreads_and(fixup && all_z) != 0;  // (also: lut is written)
+    const long total = idle ? 0 : (long)g.N * g.To * g.Ho * g.Wo * groups;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        long pos = i / groups;
-        const int wo = (int)(pos % g.Wo);
-        pos /= g.Wo;
-        const int ho = (int)(pos % g.Ho);
-        pos /= g.Ho;
-        const int to = (int)(pos % g.To);
-        const int n = (int)(pos / g.To);
-        const long origin = (((long)n * g.T + (to * g.st - g.pt)) * g.H + (ho * g.sh - g.ph)) * g.W + (wo * g.sw - g.pw);
+        if (fixup && all_z) continue;
         float d[8];
         unpack8(dout[i], d);
         float yv[8];
@@ -829,6 +843,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16* _
             }
         }
         if (!all_z) {
+            // (the position is only needed for the gather: its 64-bit divisions cost the pure streaming case, which every
+            // sane BatchNorm is, 117 us for 0.1 GB)
+            long pos = i / groups;
+            const int wo = (int)(pos % g.Wo);
+            pos /= g.Wo;
+            const int ho = (int)(pos % g.Ho);
+            pos /= g.Ho;
+            const int to = (int)(pos % g.To);
+            const int n = (int)(pos / g.To);
+            const long origin = (((long)n * g.T + (to * g.st - g.pt)) * g.H + (ho * g.sh - g.ph)) * g.W + (wo * g.sw - g.pw);
             const uint64_t packed = *(const uint64_t*)(idx + i * 8);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -841,7 +865,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16* _
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float gk = on[k] ? d[k] : 0.f;
+            const float gk = (on[k] && !(fixup && zok[k])) ? d[k] : 0.f;
             a0[k] += gk;
             a1[k] += gk * (yv[k] - mean[k]) * invstd[k];
         }
@@ -852,7 +876,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16* _
         sm[threadIdx.x * 17 + 8 + k] = a1[k];
     }
     __syncthreads();
-    if (threadIdx.x < groups) {
+    if (threadIdx.x < groups && !idle) {
         const int rl = 256 / groups;
         float* dst = sums + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * C;
         for (int k = 0; k < 16; ++k) {
@@ -1449,6 +1473,9 @@ int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const fl
     else if (mask == 3)
         VC_LAUNCH((chan_reduce_kernel<1, 3>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
                   VcBnFin{}, bf, (float*)nullptr);
+    else if (mask == 4)  // internal: vc_ew_bn_bwd_reduce_pooled
+        VC_LAUNCH((chan_reduce_kernel<1, 4>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
+                  VcBnFin{}, bf, (float*)nullptr);
     else
         VC_LAUNCH((chan_reduce_kernel<1, 2>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
                   VcBnFin{}, bf, (float*)nullptr);
@@ -1652,8 +1679,19 @@ int vc_ew_pack_dgrad_batched(const void* shadow, void* wd, const int* table, int
 int vc_ew_bn_bwd_reduce_pooled(const void* y, const void* dout, const uint8_t* idx, const void* pooled, const float* params, float* sums,
                                const VcPoolGeom& g, const VcBnBwdFin* fin, hipStream_t s) {
     const long total = (long)g.N * g.To * g.Ho * g.Wo * (g.C / 8);
+    const int groups = g.C / 8;
+    if (pooled != nullptr && groups <= 256 && 256 % groups == 0 && g.C % 64 == 0 && getenv("VC_POOLRED_GATHER") == nullptr) {
+        // the sums are a plain streaming reduction over the two pooled tensors (chan_reduce_kernel: 5-6 TB/s); the one-
+        // kernel form below spent 117 us on 0.1 GB, most of it in its 262 k float atomics.  A small second launch takes
+        // the channels that cannot be solved from z (normally none) and runs the finalize after both.
+        const int rc = vc_ew_bn_bwd_reduce(pooled, dout, nullptr, params, sums, total / groups, g.C, 4, nullptr, s);
+        if (rc) return rc;
+        VC_LAUNCH(bn_bwd_reduce_pooled_kernel, dim3(grid_for(total, 256, 256)), dim3(256), 0, s, (const bf16*)y,
+                  (const bf16x8*)dout, idx, (const bf16x8*)pooled, params, sums, g, fin ? *fin : VcBnBwdFin{}, 1);
+        return VC_CHECK_LAUNCH();
+    }
     VC_LAUNCH(bn_bwd_reduce_pooled_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, s, (const bf16*)y,
-              (const bf16x8*)dout, idx, (const bf16x8*)pooled, params, sums, g, fin ? *fin : VcBnBwdFin{});
+              (const bf16x8*)dout, idx, (const bf16x8*)pooled, params, sums, g, fin ? *fin : VcBnBwdFin{}, 0);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_bn_bwd_apply_pooled(const void* y, const void* dout, const uint8_t* idx, const float* params, const float* coef,
