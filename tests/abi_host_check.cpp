@@ -51,6 +51,14 @@ static void conv_all(int N, int Ci, int T, int H, int W, int Co, int k, int s, i
         note(vc_conv3d_fwd_act(&d, P, P, P, F, nullptr, 0, w0 ? P : nullptr, w0, nullptr));
         note(vc_conv3d_dgrad(&d, P, P, P, 0, w1 ? P : nullptr, w1, nullptr));
         note(vc_conv3d_dgrad(&d, P, P, P, 1, w1 ? P : nullptr, w1, nullptr));
+        {   // the fused form: reduction of the next BatchNorm backward and / or the masked accumulate
+            vc_bn_bwd_red red = {P, F, (const uint8_t*)P, F, (uint32_t*)P, F, F, F};
+            note(vc_conv3d_dgrad_fused(&d, P, P, P, 0, nullptr, &red, w1 ? P : nullptr, w1, nullptr));
+            red.relu_bits = nullptr;  // mask mode 2
+            note(vc_conv3d_dgrad_fused(&d, P, P, P, 1, (const uint8_t*)P, &red, w1 ? P : nullptr, w1, nullptr));
+            note(vc_conv3d_dgrad_fused(&d, P, P, P, 1, (const uint8_t*)P, nullptr, w1 ? P : nullptr, w1, nullptr));
+            note(vc_conv3d_dgrad_fused(&d, P, P, P, 0, (const uint8_t*)P, nullptr, w1 ? P : nullptr, w1, nullptr));  // refused
+        }
         note(vc_conv3d_wgrad(&d, P, P, F, w2 ? P : nullptr, w2, nullptr));
     }
     note(vc_conv3d_fwd_noalloc(&d, P, P, P, F, nullptr));
