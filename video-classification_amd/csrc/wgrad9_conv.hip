@@ -342,7 +342,10 @@ int vc_wgrad9_plan(long M, int W, int Cs, int Co, int ndt, int* rows_per_split) 
     const int CH = 128;  // slices are whole chunks of either form
     const long tiles = (long)ndt * (Cs / 64) * (Co / 64);
     static const long target_env = getenv("VC_WGRAD9_TARGET") ? atol(getenv("VC_WGRAD9_TARGET")) : 0;
-    const long target = target_env > 0 ? target_env : (wgrad9_four_waves(W) ? 512 : 256);
+    // 192 workgroups of eight waves, not one per CU: the weight gradients run on the side stream, and the quarter of
+    // the CUs they leave free takes the main stream's kernels (measured over 96 .. 512: R3D-18 step 4.95 ms at 256,
+    // 4.90 at 192, 4.98 at 128; R3D-50 10.45 / 10.39 / 10.50) -- and a slice fewer means a slab fewer to reduce
+    const long target = target_env > 0 ? target_env : (wgrad9_four_waves(W) ? 512 : 192);
     long splits = (target + tiles / 2) / tiles;
     const long maxs = (M + 4 * CH - 1) / (4 * CH);  // at least 4 chunks per slice
     if (splits > maxs) splits = maxs;

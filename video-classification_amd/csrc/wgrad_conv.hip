@@ -255,10 +255,12 @@ int vc_wgrad_splits(int M, int Co, int nblk, int* rows_per_split) {
     const int nb = wide ? 2 : 4;
     const int bco = wide ? 128 : 64;
     const long tiles = (long)((nblk + nb - 1) / nb) * (Co / bco);
-    // aim for ~512 workgroups (two per CU), at least 4 chunks (256 rows) per split.  Every split costs a slab of the
-    // whole gradient (written, then read by the reduce): 512 against 1024 measured 15-25 % faster on the 1x1x1 and
-    // the strided 3x3x3 shapes of R3D-18/50 and never slower
-    static const long target = getenv("VC_WGRAD_TARGET") ? atol(getenv("VC_WGRAD_TARGET")) : 512;
+    // aim for ~192 workgroups, at least 4 chunks (256 rows) per split.  Every split costs a slab of the whole gradient
+    // (written, then read by the reduce): in isolation 512 against 1024 measured 15-25 % faster on the 1x1x1 and the
+    // strided 3x3x3 shapes of R3D-18/50; in the step these launches run on the side stream beside the main stream's
+    // kernels, and 192 -- which leaves CUs to those and writes fewer slabs -- beat the 512 that fill every CU twice:
+    // R3D-50 step 10.49 -> 10.37 ms, R3D-18 4.87 -> 4.86 (sweep 128 .. 768)
+    static const long target = getenv("VC_WGRAD_TARGET") ? atol(getenv("VC_WGRAD_TARGET")) : 192;
     long splits = (target + tiles - 1) / tiles;
     const long maxsplits = (M + 255) / 256;
     if (splits > maxsplits) splits = maxsplits;
