@@ -10,10 +10,10 @@ mkdir -p $O
 step() { echo "== $1" >&2; }
 step "bench R3D-18" && timeout -k 10 300 python3 bench.py --profile-kernels > $O/bench.json 2> $O/conv_table.txt || exit 1
 step "bench R3D-50" && timeout -k 10 300 python3 bench.py --model 50 --profile-kernels --no-cpu-baseline > $O/bench_r3d50.json 2> $O/conv_table_r3d50.txt || exit 1
-step "trace R3D-18" && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace18 -o p -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/trace18.log 2>&1 || exit 1
-python3 scripts/prof_summary.py $O/trace18/p_results.db --steps 13 --top 60 --csv $O/kernel_stats.csv > $O/kernel_stats.txt
-step "trace R3D-50" && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace50 -o p -- python3 bench.py --model 50 --steps 10 --warmup 3 --no-cpu-baseline > $O/trace50.log 2>&1 || exit 1
-python3 scripts/prof_summary.py $O/trace50/p_results.db --steps 13 --top 70 --csv $O/kernel_stats_r3d50.csv > $O/kernel_stats_r3d50.txt
+step "trace R3D-18" && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace18 -o p -- python3 bench.py --steps 27 --warmup 3 --no-cpu-baseline > $O/trace18.log 2>&1 || exit 1
+python3 scripts/prof_summary.py $O/trace18/p_results.db --steps 30 --top 60 --csv $O/kernel_stats.csv > $O/kernel_stats.txt
+step "trace R3D-50" && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace50 -o p -- python3 bench.py --model 50 --steps 27 --warmup 3 --no-cpu-baseline > $O/trace50.log 2>&1 || exit 1
+python3 scripts/prof_summary.py $O/trace50/p_results.db --steps 30 --top 70 --csv $O/kernel_stats_r3d50.csv > $O/kernel_stats_r3d50.txt
 step "pmc" && bash scripts/pmc_check.sh $TAG > $O/pmc.log 2>&1 || { tail -5 $O/pmc.log; exit 1; }
 python3 scripts/pmc_summary.py gpurun_out/pmc_$TAG --csv $O/pmc_per_kernel.csv > $O/pmc_summary.txt
 python3 scripts/roofline_table.py $O/kernel_stats.csv $O/pmc_per_kernel.csv > $O/roofline_table.txt
