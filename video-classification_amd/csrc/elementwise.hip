@@ -948,8 +948,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pooled_tiled_kernel(const bf
     const int prow = g.Wo * groups;  // 16-byte vectors per pooled row
     bf16x8* sD = (bf16x8*)pool_sm;                             // [2][2][prow]
     uint64_t* sI = (uint64_t*)(pool_sm + (size_t)4 * prow * 16);  // [2][2][prow]
-    const int bh = blockIdx.x % nbh;
-    const int q = blockIdx.x / nbh;
+    // neighbouring workgroups stage the same pooled rows (each row serves 2 x 2 of them): XCD k takes the k-th contiguous
+    // eighth of the workgroups, so that the re-reads are L2 hits (they were 0.3 GB of this launch's HBM reads for 76 MB
+    // of pooled tensors; workgroups are dealt round-robin to the 8 XCDs)
+    unsigned bid = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
+    const int bh = (int)bid % nbh;
+    const int q = (int)bid / nbh;
     const int bt = q % nbt, n = q / nbt;
     const int a = bt - 1, b = bh - 1;
     for (int s = 0; s < 4; ++s) {
