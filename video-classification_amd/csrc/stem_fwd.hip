@@ -34,21 +34,26 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #ifndef VC_STEMF_NT
 #define VC_STEMF_NT 2  // 16-position tiles per wave and frame: 2 -> 7 waves of 32 positions, 4 -> 4 waves of 64
 #endif
+#ifndef VC_STEMF_FG
+#define VC_STEMF_FG 1  // frame pairs in flight: 2 -> two groups of waves, each on its own pair of frames (with NT = 4)
+#endif
 constexpr int NT = VC_STEMF_NT;
+constexpr int FG = VC_STEMF_FG;
 constexpr int PW = NT * 16;          // positions per wave and frame
-constexpr int NWAVE = NT == 2 ? 7 : 4;
+constexpr int WPG = NT == 2 ? 7 : 4; // waves per group: they share a chunk of WPG * PW positions of the group's two frames
+constexpr int NWAVE = WPG * FG;
 constexpr int WPITCH = 416;          // bytes per weight row in LDS: 384 data + 32 pad (conflict-free ds_read_b128)
 constexpr int WPIECES = 26;          // 64 rows x 26 slots of 16 bytes = 26 pieces of 1 KiB
 constexpr int WBUF = WPIECES * 1024;
-constexpr int NSLOT = 8;             // plane ring: the 8 planes of a frame pair; the next pair's two new planes
-                                     // replace planes t, t+1 once temporal tap 1 is done with them
-constexpr int NWB = 3;               // weight tiles in flight: tap g is computed while g+1 and g+2 stream in
+constexpr int NSLOT = 6 + 2 * FG;    // plane ring: the 8 planes of a frame pair (10 of two pairs); the next step's new
+                                     // planes replace the oldest ones once the taps that read them are done
+constexpr int NWB = FG == 2 ? 2 : 3; // weight tiles in flight: tap g is computed while g+1 (and g+2) stream in
 constexpr int WPW = (WPIECES + NWAVE - 1) / NWAVE;  // weight DMA instructions per wave and tile (26 pieces + dummies)
 constexpr int W_OFF = 0;
 constexpr int DUMMY_OFF = NWB * WBUF;  // 1 KiB that the dummy DMA instructions land in
 constexpr int PL_OFF = NWB * WBUF + 1024;
 
-__global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NT == 2 ? 2 : 1, 2))) void stem_fwd_kernel(
+__global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NWAVE > 4 ? 2 : 1, 2))) void stem_fwd_kernel(
     const VcStemFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NT =
     int mloc[NT], posoff[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        mloc[nt] = wave * PW + nt * 16 + l15;
+        mloc[nt] = (wave % WPG) * PW + nt * 16 + l15;
         const int hl = mloc[nt] / p.Wo;
         const int w = mloc[nt] - hl * p.Wo;
         posoff[nt] = mloc[nt] < CP ? hl * RP + w * 24 : 0;
@@ -77,6 +82,7 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NT =
         koff[ks] = ah * RP + (k - ah * 48) * 2;
     }
     const int aoff = l15 * WPITCH + lg * 16;
+    const int fg2 = 2 * (wave / WPG);  // this wave's frames of a step: t + fg2, t + fg2 + 1
 
     f32x4 ssum[4], ssq[4];  // BatchNorm partial sums of this lane's channels co = a*16 + lg*4 + j (packed fp32 math)
     f32x4 sshift[4];        // their shift (bn_fin.h), 0 without one
@@ -123,12 +129,12 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NT =
         const int h0 = hg * p.RH;
         const int cpv = min(p.RH, p.Ho - h0) * p.Wo;  // valid positions of this row group
         __syncthreads();  // the previous unit's last reads are done: ring and weight buffers may be refilled
-        for (int tp = t0; tp < t0 + 8; ++tp) issue_plane(n, tp, h0);
-        const int nsteps = ((t1 - t0 + 1) >> 1) * 7;  // temporal-tap steps of this unit
+        for (int tp = t0; tp < t0 + NSLOT; ++tp) issue_plane(n, tp, h0);
+        const int nsteps = ((t1 - t0 + 2 * FG - 1) / (2 * FG)) * 7;  // temporal-tap steps of this unit
         issue_w(0, 0);
-        if (nsteps > 1) issue_w(1, 1);
+        if (NWB == 3 && nsteps > 1) issue_w(1, 1);
         int g = 0;  // step counter of the unit: weight tile of step g sits in buffer g % NWB
-        for (int t = t0; t < t1; t += 2) {
+        for (int t = t0; t < t1; t += 2 * FG) {
             f32x4 acc[4][2][NT];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
@@ -141,23 +147,35 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NT =
                 // tile g has landed once at most the younger tile g+1 is in flight; the step after the plane
                 // refill (kt == 3) and the unit's last step drain everything
                 static_assert(WPW == 4 || WPW == 7, "counted wait below");
-                if (kt == 3 || g + 1 >= nsteps) __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+                // (two frame pairs: one tile ahead only, and the plane refills of the step before are waited for as well)
+                if (FG == 2 || kt == 3 || g + 1 >= nsteps) __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
                 else __builtin_amdgcn_s_waitcnt(WPW == 4 ? 0x0074 : 0x0077);         // vmcnt(WPW) lgkmcnt(0)
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 const int wbuf = g % NWB;
 #if !(VC_STEMF_ABLATE & 2)
-                if (kt == 2 && t + 2 < t1) {  // planes t and t+1 are dead after tap 1: the next pair's new planes go there
-                    issue_plane(n, t + 8, h0);
-                    issue_plane(n, t + 9, h0);
+                if (FG == 1) {
+                    if (kt == 2 && t + 2 < t1) {  // planes t and t+1 are dead after tap 1: the next pair's new planes go there
+                        issue_plane(n, t + 8, h0);
+                        issue_plane(n, t + 9, h0);
+                    }
+                } else if (t + 4 < t1) {
+                    // planes t .. t+3 are dead after tap 3 (plane t+j is read by frame t+i at tap j-i): the next step's four
+                    // new planes take their slots, two per step so that the DMA queue is not hit by all of them at once
+                    if (kt == 4) issue_plane(n, t + 10, h0), issue_plane(n, t + 11, h0);
+                    if (kt == 5) issue_plane(n, t + 12, h0), issue_plane(n, t + 13, h0);
                 }
 #endif
 #if !(VC_STEMF_ABLATE & 1)
-                if (g + 2 < nsteps) issue_w((kt + 2) % 7, (g + 2) % NWB);  // buffer of tile g-1, read one step ago
+                if (NWB == 3) {
+                    if (g + 2 < nsteps) issue_w((kt + 2) % 7, (g + 2) % NWB);  // buffer of tile g-1, read one step ago
+                } else {
+                    if (g + 1 < nsteps) issue_w((kt + 1) % 7, (g + 1) % NWB);  // buffer of tile g-1, read one step ago
+                }
 #endif
                 const char* sW = smem + W_OFF + wbuf * WBUF + aoff;
-                const char* pl0 = smem + PL_OFF + ((t + kt) % NSLOT) * PLB;
-                const char* pl1 = smem + PL_OFF + ((t + 1 + kt) % NSLOT) * PLB;
+                const char* pl0 = smem + PL_OFF + ((t + fg2 + kt) % NSLOT) * PLB;
+                const char* pl1 = smem + PL_OFF + ((t + fg2 + 1 + kt) % NSLOT) * PLB;
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) {
                     bf16x8 fa[4];
@@ -176,12 +194,24 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NT =
                                 acc[a][f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[a][f][nt], 0, 0, 0);
                         }
                 }
+                if (NT == 4) {
+                    // pin the read / MFMA interleave of the tap (one basic block): per k-step 4 weight + 16 image reads for
+                    // 32 MFMAs; the first k-step's weights and two image fragments go out up front, then 7 reads per
+                    // three fragments' 12 MFMAs (left alone the compiler reads each fragment right before its MFMAs)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                    for (int i = 0; i < 48; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        if (i % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                }
             }
             // ---- acc[a][f][nt][j] = Y[frame t+f][position mloc[nt]][co = a*16 + lg*4 + j]
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-                if (t + f >= t1) continue;
-                const long mrow = ((long)(n * p.T + t + f) * p.Ho + h0) * p.Wo;
+                if (t + fg2 + f >= t1) continue;
+                const long mrow = ((long)(n * p.T + t + fg2 + f) * p.Ho + h0) * p.Wo;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     if (mloc[nt] >= cpv) continue;
@@ -241,12 +271,12 @@ int vc_stem_fwd_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcSte
     const int RP = Wp * 24;
     int best_rh = 0;
     double best_eff = 0.0;
-    for (int RH = 1; RH <= Ho && RH * Wo <= NWAVE * PW; ++RH) {
+    for (int RH = 1; RH <= Ho && RH * Wo <= WPG * PW; ++RH) {
         const int pieces = ((RH + 3) * RP + 1023) / 1024;
         const long lds = (long)NWB * WBUF + 1024 + (long)NSLOT * pieces * 1024;
         if (lds > 160 * 1024) break;
         const int nhg = (Ho + RH - 1) / RH;
-        const double eff = ((double)Ho * Wo / ((double)nhg * NWAVE * PW)) * ((double)RH / (RH + 1.0));
+        const double eff = ((double)Ho * Wo / ((double)nhg * WPG * PW)) * ((double)RH / (RH + 1.0));
         if (eff > best_eff) best_eff = eff, best_rh = RH;
     }
     if (best_rh == 0) return 0;
@@ -262,7 +292,7 @@ int vc_stem_fwd_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcSte
         const long units = (long)N * p.nhg * nr;
         const long wgs = units < target ? units : target;
         const long per = (units + wgs - 1) / wgs;
-        const double cost = (double)per * ((TR + 1) / 2 + 0.7);  // frame pairs + ring start-up
+        const double cost = (double)per * ((TR + 2 * FG - 1) / (2 * FG) + 0.7);  // steps (FG frame pairs each) + ring start-up
         if (cost < best_cost) best_cost = cost, p.ntr = nr, p.TR = TR;
     }
     p.units = N * p.nhg * p.ntr;
