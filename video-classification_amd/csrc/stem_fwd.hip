@@ -29,7 +29,11 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 #ifndef VC_STEMF_ABLATE
-#define VC_STEMF_ABLATE 0  // timing experiments only: 1 = weight tiles not refilled, 2 = image planes not refilled
+#define VC_STEMF_ABLATE 0  // timing experiments only: 1 = weight tiles not refilled, 2 = image planes not refilled,
+                           // 4 / 8 = no image / weight fragment reads, 16 = no MFMAs, 32 = no per-tap barrier
+#endif
+#ifndef VC_STEMF_B128
+#define VC_STEMF_B128 0  // image fragments as one 8-byte-aligned ds_read_b128 instead of two ds_read_b64
 #endif
 #ifndef VC_STEMF_NT
 #define VC_STEMF_NT 2  // 16-position tiles per wave and frame: 2 -> 7 waves of 32 positions, 4 -> 4 waves of 64
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NWAV
                 // (two frame pairs: one tile ahead only, and the plane refills of the step before are waited for as well)
                 if (FG == 2 || kt == 3 || g + 1 >= nsteps) __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
                 else __builtin_amdgcn_s_waitcnt(WPW == 4 ? 0x0074 : 0x0077);         // vmcnt(WPW) lgkmcnt(0)
-                __builtin_amdgcn_s_barrier();
+                if (!(VC_STEMF_ABLATE & 32)) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 const int wbuf = g % NWB;
 #if !(VC_STEMF_ABLATE & 2)
@@ -180,18 +184,33 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NWAV
                 for (int ks = 0; ks < 6; ++ks) {
                     bf16x8 fa[4];
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) fa[a] = *(const bf16x8*)(sW + a * 16 * WPITCH + ks * 64);
+                    for (int a = 0; a < 4; ++a) {
+                        if (VC_STEMF_ABLATE & 8) asm volatile("" : "=v"(fa[a]));  // timing only: no weight fragment reads
+                        else fa[a] = *(const bf16x8*)(sW + a * 16 * WPITCH + ks * 64);
+                    }
 #pragma unroll
                     for (int f = 0; f < 2; ++f)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
                             const char* bp = (f ? pl1 : pl0) + posoff[nt] + koff[ks];
-                            const bf16x4 lo = *(const bf16x4*)bp;
-                            const bf16x4 hi = *(const bf16x4*)(bp + 8);
-                            const bf16x8 fb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                            bf16x8 fb;
+                            if (VC_STEMF_ABLATE & 4) {  // timing only: no image fragment reads
+                                asm volatile("" : "=v"(fb));
+                            } else {
+#if VC_STEMF_B128
+                                typedef bf16x8 __attribute__((aligned(8))) bf16x8_a8;
+                                fb = *(const bf16x8_a8*)bp;  // one 16-byte read at 8-byte alignment
+#else
+                                const bf16x4 lo = *(const bf16x4*)bp;
+                                const bf16x4 hi = *(const bf16x4*)(bp + 8);
+                                fb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#endif
+                            }
 #pragma unroll
-                            for (int a = 0; a < 4; ++a)
-                                acc[a][f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[a][f][nt], 0, 0, 0);
+                            for (int a = 0; a < 4; ++a) {
+                                if (VC_STEMF_ABLATE & 16) asm volatile("" : "+v"(acc[a][f][nt]) : "v"(fa[a]), "v"(fb));  // no MFMA
+                                else acc[a][f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[a][f][nt], 0, 0, 0);
+                            }
                         }
                 }
                 if (NT == 4) {
