@@ -35,6 +35,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #ifndef VC_STEMF_B128
 #define VC_STEMF_B128 0  // image fragments as one 8-byte-aligned ds_read_b128 instead of two ds_read_b64
 #endif
+#ifndef VC_STEMF_PIPE
+#define VC_STEMF_PIPE 1  // explicit two-set fragment pipeline over the k-steps of a tap (0: the plain loop; 0.532 -> 0.510 ms in the step)
+#endif
 #ifndef VC_STEMF_NT
 #define VC_STEMF_NT 2  // 16-position tiles per wave and frame: 2 -> 7 waves of 32 positions, 4 -> 4 waves of 64
 #endif
@@ -180,6 +183,44 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NWAV
                 const char* sW = smem + W_OFF + wbuf * WBUF + aoff;
                 const char* pl0 = smem + PL_OFF + ((t + fg2 + kt) % NSLOT) * PLB;
                 const char* pl1 = smem + PL_OFF + ((t + fg2 + 1 + kt) % NSLOT) * PLB;
+#if VC_STEMF_PIPE
+                // explicit software pipeline over the six k-steps of the tap: the fragments of k-step ks+1 are read while
+                // the MFMAs of ks run (two fragment sets), the interleave pinned below
+                bf16x8 fa[2][4], fb[2][2][NT];
+                auto load_ks = [&](int ks, bf16x8 (&qa)[4], bf16x8 (&qb)[2][NT]) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) qa[a] = *(const bf16x8*)(sW + a * 16 * WPITCH + ks * 64);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const char* bp = (f ? pl1 : pl0) + posoff[nt] + koff[ks];
+                            const bf16x4 lo = *(const bf16x4*)bp;
+                            const bf16x4 hi = *(const bf16x4*)(bp + 8);
+                            qb[f][nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                };
+                load_ks(0, fa[0], fb[0]);
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) {
+                    if (ks + 1 < 6) load_ks(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int a = 0; a < 4; ++a)
+                                acc[a][f][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks & 1][a], fb[ks & 1][f][nt], acc[a][f][nt], 0, 0, 0);
+                }
+                if (NT == 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);  // k-step 0: 4 weight + 8 image reads
+#pragma unroll
+                    for (int i = 0; i < 24; ++i) {  // 24 groups of 4 MFMAs; the 60 reads of k-steps 1..5 ride along, 3 per group
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        if (i < 20) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    }
+                }
+#else
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) {
                     bf16x8 fa[4];
@@ -213,6 +254,7 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NWAV
                             }
                         }
                 }
+#endif
                 if (NT == 4) {
                     // pin the read / MFMA interleave of the tap (one basic block): per k-step 4 weight + 16 image reads for
                     // 32 MFMAs; the first k-step's weights and two image fragments go out up front, then 7 reads per
