@@ -18,6 +18,9 @@
 // per-channel sum / sum-of-squares (the BatchNorm batch statistics) reduced over the tile
 // from the fp32 accumulators and added to one of VC_STAT_REPLICAS copies with float atomics.
 #include "common.h"
+#ifndef VC_IGEMM_PIPE
+#define VC_IGEMM_PIPE 1  // two fragment sets per chunk with a pinned read / MFMA interleave (0: the unpinned loop)
+#endif
 #include "kernels.h"
 
 namespace {
@@ -230,6 +233,34 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
 
             const char* sW = smem + buf * Cfg::BUF_BYTES;
             const char* sX = sW + BCO * ROWB;
+#if VC_IGEMM_PIPE
+            {   // both k-steps' fragments as two sets, the second read behind the first's MFMAs (pinned)
+                bf16x8 fa[2][4], fb[2][4];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int slot = ((ks << 2) + lg) ^ lswz;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        fa[ks][a] = *(const bf16x8*)(sW + (wco * 64 + a * 16 + l15) * ROWB + (slot << 4));
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        fb[ks][b] = *(const bf16x8*)(sX + (wm * 64 + b * 16 + l15) * ROWB + (slot << 4));
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][a], fb[ks][b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 fa[4], fb[4];
@@ -246,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
                     for (int b = 0; b < 4; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
             }
+#endif
             ti = nti;
             c0 = nc0;
             buf ^= 1;
