@@ -103,6 +103,40 @@ def test_eval_mode_matches_oracle():
     assert torch.equal(lo.argmax(1).cpu(), lo_ref.argmax(1))
 
 
+@pytest.mark.parametrize("depth", [34, 101, 152])
+def test_other_depths_of_resnet_spec(depth):
+    """backbone.py:188-192 lists five depths; 18 and 50 carry the benchmarks, the other three share their kernels
+    (BasicBlock [3, 4, 6, 3]; Bottleneck [3, 4, 23, 3] and [3, 8, 36, 3]).  One training step: logits against the fp32
+    oracle with the oracle's bf16-storage emulation as the yardstick for what 100+ layers of bf16 activations cost at
+    random initialisation (as test_golden_gpu does for R3D-50), loss, finite gradients for every parameter."""
+    from oracle.r3d_torch import synthetic_batch, forward_emulated
+    oracle, prod, cfg = build_pair(depth, 101)
+    x, y = synthetic_batch(3, 8, 64, 64, 101, 7 + depth)
+    oracle.train()
+    prod.train()
+    sd0 = {k: v.clone() for k, v in oracle.state_dict().items()}
+    with torch.no_grad():
+        lo_emu = forward_emulated(oracle, x)
+    oracle.load_state_dict(sd0)
+    with torch.no_grad():
+        lo_ref = oracle(x)
+    loss_ref = F.cross_entropy(lo_ref, y)
+    _, lo, _ = prod(x.cuda())
+    loss = F.cross_entropy(lo, y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    e, e_emu = rel_l2(lo.detach(), lo_ref), rel_l2(lo_emu, lo_ref)
+    print("R3D-%d train-mode logits rel-L2 %.3e (bf16-storage emulation %.3e)" % (depth, e, e_emu))
+    assert e <= max(5e-2, 1.25 * e_emu + 5e-3)
+    assert abs(float(loss.detach()) - float(loss_ref)) <= 3e-2 * abs(float(loss_ref)), (float(loss.detach()), float(loss_ref))
+    names = [n for n, _ in oracle.named_parameters()]
+    got = {n.replace("clf_haed.", "clf_head."): p for n, p in prod.named_parameters()}
+    assert sorted(got) == sorted(names)
+    for n, p in got.items():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+        assert float(p.grad.abs().max()) > 0, n
+
+
 def test_grad_accumulation_and_zero_grad():
     from oracle.r3d_torch import synthetic_batch
     _, prod, _ = build_pair(18, 101)

@@ -987,7 +987,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pooled_tiled_kernel(const bf
                 const int jw = j0 + threadIdx.x / groups;
                 const int w = 2 * jw + par;
                 if (w >= g.W) continue;
-                const bf16x8 yv = yrow[w * groups + cg];
+                // y is read once and dy written once (0.8 GB): keep them from evicting the pooled rows, which the
+                // neighbouring workgroups re-read from L2
+                const bf16x8 yv = __builtin_nontemporal_load(&yrow[w * groups + cg]);
                 float d[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) d[k] = 0.f;
@@ -1014,7 +1016,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pooled_tiled_kernel(const bf
                     const float xhat = (f[k] - kc.mean[k]) * kc.invstd[k];
                     o[k] = kc.scale[k] * (gk - kc.c1[k] - xhat * kc.c2[k]);
                 }
-                drow[w * groups + cg] = pack8(o);
+                __builtin_nontemporal_store(pack8(o), &drow[w * groups + cg]);
             }
         }
     }
