@@ -82,6 +82,7 @@ struct VcWgradParams {
     float* partial;  // nullable: fp32 slabs [splits][Co][Kw] instead of atomics
     long long partial_stride;
     VcTap taps[32];
+    int xcd_map;  // 1: XCD k takes the k-th contiguous share of the (z, y, x) workgroup order (wgrad_conv.hip)
 };
 
 // halo_conv.hip: stride-1 conv with the activation halo resident in LDS

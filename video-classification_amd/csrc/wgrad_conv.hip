@@ -41,8 +41,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int co0 = blockIdx.y * BCO;
-    const int mb = blockIdx.z * p.rows_per_split;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and the workgroups of one slice of m -- the
+    // co blocks and the tap / ci groups -- read the same dY and x rows: XCD k takes the k-th contiguous share of the
+    // (z, y, x) order, so that a slice's workgroups meet in one L2 (as in wgrad9_conv.hip).  Without it the pointwise
+    // layers of R3D-50 drew 1.7x their algorithmic bytes from below the L2.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_map) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
+        const unsigned k = lin & 7u, base = total >> 3, rem = total & 7u;
+        const unsigned logical = k * base + (k < rem ? k : rem) + (lin >> 3);
+        bx = logical % gridDim.x;
+        const unsigned t = logical / gridDim.x;
+        by = t % gridDim.y;
+        bz = t / gridDim.y;
+    }
+    const int co0 = by * BCO;
+    const int mb = bz * p.rows_per_split;
     const int mend = min(p.M, mb + p.rows_per_split);
     const int nchunks = (mend - mb + 63) >> 6;
 
@@ -54,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
     bool b_ok[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int cb = blockIdx.x * NB + b;
+        const int cb = (int)bx * NB + b;
         b_ok[b] = cb < nblk;
         if (MODE == 0) {
             const int tap = b_ok[b] ? cb / cpt : 0;
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int g = (blockIdx.x * NB + b) * 8 + lsub + 4 * h;
+                const int g = ((int)bx * NB + b) * 8 + lsub + 4 * h;
                 const int j = g / 6;
                 const int within = (g - j * 6) * 8;
                 st_soff[b][h] = (((j >> 2) * p.Hs + (j & 3)) * p.Ws) * p.Cs + within;
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
     float* dst = p.dw;
     int how = 0;  // 0 atomics, 1 plain += (single split owns the element), 2 plain store into a slab
     if (p.partial != nullptr && p.splits > 1) {
-        dst = p.partial + (size_t)blockIdx.z * p.partial_stride;
+        dst = p.partial + (size_t)bz * p.partial_stride;
         how = 2;
     } else if (p.splits <= 1) {
         how = 1;
@@ -286,6 +301,8 @@ int vc_launch_wgrad(const VcWgradParams& p_in, int mode, hipStream_t stream) {
     const int splits = vc_wgrad_splits(p.M, p.Co, nblk, &rps);
     p.rows_per_split = rps;
     p.splits = splits;
+    static const bool no_xcd_map = getenv("VC_NO_XCD_MAP") != nullptr || getenv("VC_WGRAD_NO_XCD_MAP") != nullptr;
+    p.xcd_map = no_xcd_map ? 0 : 1;
     if (mode == 1) return launch_wgrad<64, 4, 1>(p, splits, stream);
     if (wide) return launch_wgrad<128, 2, 0>(p, splits, stream);
     return launch_wgrad<64, 4, 0>(p, splits, stream);
