@@ -65,6 +65,7 @@ struct VcPwParams {
     const uint8_t* red_bits;    // [M * Cn / 8] (mask mode 3), or null: scale * red_y + shift > 0 (mask mode 2)
     float* red_sums;            // [VC_STAT_REPLICAS][2][Cn]
     VcBnBwdFin red_fin;
+    int xcd_map;  // 1: the co blocks of a row tile are neighbours in an XCD-contiguous workgroup order (pw_conv.hip)
 };
 int vc_launch_pw(const VcPwParams& p, hipStream_t stream);
 

@@ -6,6 +6,8 @@
 // row table -- because the Bottleneck's pointwise convs are bandwidth-bound and what limits a bandwidth-bound kernel
 // is the bytes it keeps in flight: the general kernel holds ~230 VGPRs (two workgroups per CU); this one is built for
 // WPE waves per SIMD so that three or four workgroups fit, each with its tile's loads outstanding.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -38,7 +40,20 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int co0 = blockIdx.y * BCO;
+    // The Cn / BCO workgroups of a row tile read the same activation rows.  In the plain (x, y) order they sit gridDim.x
+    // apart and land on different XCDs (gridDim.x is rarely a multiple of 8), so each XCD's L2 fetched the rows for
+    // itself: up to Cn / BCO = 16 reads of the input of a P -> 4P layer.  Here XCD k takes the k-th contiguous share of
+    // the (x, y fastest) order: the co blocks of a tile are neighbours in one L2.
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_map) {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned lin = bx + gridDim.x * by;
+        const unsigned k = lin & 7u, base = total >> 3, rem = total & 7u;
+        const unsigned logical = k * base + (k < rem ? k : rem) + (lin >> 3);
+        bx = logical / gridDim.y;
+        by = logical - bx * gridDim.y;
+    }
+    const int co0 = (int)by * BCO;
     const int lrow = tid >> 3;
     const int lslot = (tid & 7) ^ ((lrow >> 1) & 7);
     const int wco = wave % Cfg::WCO, wm = wave / Cfg::WCO;
@@ -64,7 +79,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) ra0[k] = ra1[k] = 0.f;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = (int)bx; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * BM;
         unsigned woff_t = woff;  // (opaque per tile: hoisted out of the tile loop, the pieces' 64-bit addresses were spills)
         int lrow_t = lrow;
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
             float v = 0.f;
 #pragma unroll 8
             for (int rr = 0; rr < RSTEP; ++rr) v += sm[(rr * PPR + gg) * 17 + k];
-            float* srep = sums + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
+            float* srep = sums + (size_t)(bx & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
             atomicAdd(srep + (k < 8 ? 0 : p.Cn) + co0 + gg * 8 + (k & 7), v);
         }
     } else if (sums != nullptr) {
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
             }
         }
         __syncthreads();
-        float* srep = sums + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
+        float* srep = sums + (size_t)(bx & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
         for (int i = tid_e; i < 2 * BCO; i += 256) {
             const int mom = i / BCO, c = i - mom * BCO;
             float v = 0.f;
@@ -320,9 +335,9 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
     __syncthreads();  // also: every thread is done with the reduction scratch at the head of smem
     if (tid_e == 0) {
         unsigned last = 0u;
-        const unsigned t = __hip_atomic_fetch_add(ticket + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(ticket + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == gridDim.x - 1u) {
-            __hip_atomic_store(ticket + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ticket + by, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = 1u;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -396,8 +411,11 @@ int launch_pw(const VcPwParams& p, hipStream_t stream) {
             (void)hipFuncSetAttribute((const void*)pw_kernel<BCO, BM, WPE, RED>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_2);
         });
     }
+    VcPwParams q = p;
+    static const bool no_xcd_map = getenv("VC_NO_XCD_MAP") != nullptr || getenv("VC_PW_NO_XCD_MAP") != nullptr;
+    q.xcd_map = (grid.y > 1 && !no_xcd_map) ? 1 : 0;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((pw_kernel<BCO, BM, WPE, RED>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((pw_kernel<BCO, BM, WPE, RED>), grid, dim3(256), lds, stream, q);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         vc_set_error("pointwise conv launch failed: %s", hipGetErrorString(e));
