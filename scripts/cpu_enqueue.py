@@ -30,3 +30,13 @@ for _ in range(10):
     torch.cuda.synchronize(); t0 = time.perf_counter(); step(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     ts.append((t1 - t0, t2 - t0))
 print("host enqueue ms: median %.3f; step ms (enqueue + drain): median %.3f" % (1e3 * sorted(t[0] for t in ts)[5], 1e3 * sorted(t[1] for t in ts)[5]))
+if os.environ.get("VC_ENQUEUE_PROFILE") == "1":  # where the host time of a step goes (cProfile, 20 steps)
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    pr.enable()
+    for _ in range(20):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
