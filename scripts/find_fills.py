@@ -1,5 +1,5 @@
 """Which Python lines issue the small fill / copy launches of a training step?  (torch.profiler with stacks.)
-usage (GPU box, repo root): python scripts/find_fills.py [18|50]"""
+usage (GPU box, repo root): python scripts/find_fills.py [18|50] [eval]"""
 import collections
 import os
 import sys
@@ -34,6 +34,13 @@ def main():
         loss.backward()
         optimizer.step()
 
+    if len(sys.argv) > 2 and sys.argv[2] == "eval":
+        model.eval()
+
+        def step():  # noqa: F811
+            with torch.no_grad():
+                model(x)
+
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -51,7 +58,9 @@ def main():
         setattr(owner, name, f)
 
     for owner, name in ((torch.Tensor, "zero_"), (torch.Tensor, "fill_"), (torch.Tensor, "copy_"), (torch, "zeros"),
-                        (torch, "zeros_like"), (torch, "full"), (torch, "ones"), (torch, "tensor")):
+                        (torch, "zeros_like"), (torch, "full"), (torch, "ones"), (torch, "tensor"), (torch.Tensor, "to"),
+                        (torch.Tensor, "cuda"), (torch.Tensor, "contiguous"), (torch.Tensor, "clone"), (torch.Tensor, "float"),
+                        (torch, "as_tensor"), (torch, "empty"), (torch, "empty_like")):
         wrap(owner, name)
     step()
     torch.cuda.synchronize()

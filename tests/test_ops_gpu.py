@@ -326,10 +326,11 @@ def test_maxpool_fwd_bwd(shape, fused_bn):
         assert rel_l2(from_nthwc(din), a.grad) <= TOL_BF16
 
 
-def test_avgpool_linear():
+@pytest.mark.parametrize("N,C,S,K", [(5, 512, 16, 101), (64, 2048, 1, 400), (3, 64, 2, 7), (9, 128, 4, 4)])
+def test_avgpool_linear(N, C, S, K):
+    """the head: ragged sample / class counts (the kernels work on groups of four of each), the R3D-18 and R3D-50 heads"""
     _need_gpu()
     from vc3d import ops
-    N, C, S, K = 5, 512, 16, 101
     g = torch.Generator().manual_seed(5)
     x = bf16_round(torch.randn(N, S, C, generator=g))
     feat = ops.gavgpool_fwd(x.to(torch.bfloat16).cuda(), N, S, C)
