@@ -176,6 +176,52 @@ def test_cpu_input_raises():
         prod(torch.zeros(1, 3, 4, 32, 32))
 
 
+@pytest.mark.parametrize("n,t,h,w", [(1, 3, 34, 50), (2, 7, 98, 130), (5, 2, 66, 34), (7, 4, 48, 80), (1, 16, 112, 112)])
+def test_unusual_clip_shapes(n, t, h, w):
+    """one clip, odd frame counts, non-square and not-multiple-of-16 crops (ragged tiles in every kernel): a training step
+    and the eval-mode logits against the oracle (tests/shape_sweep.py: measured <= 3.5e-2 / 2.1e-2)"""
+    from oracle.r3d_torch import synthetic_batch
+    oracle, prod, _ = build_pair(18, 101)
+    x, y = synthetic_batch(n, t, h, w, 101, 11)
+    oracle.train()
+    prod.train()
+    with torch.no_grad():
+        lo_ref = oracle(x)
+    loss_ref = F.cross_entropy(lo_ref, y)
+    _, lo, _ = prod(x.cuda())
+    loss = F.cross_entropy(lo, y.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel_l2(lo.detach(), lo_ref) <= 6e-2
+    assert abs(float(loss.detach()) - float(loss_ref)) <= 2e-2 * float(loss_ref)
+    assert all(bool(torch.isfinite(p.grad).all()) for p in prod.parameters())
+    oracle.eval()
+    prod.eval()
+    with torch.no_grad():
+        assert rel_l2(prod(x.cuda())[1], oracle(x)) <= 4e-2
+
+
+def test_one_value_per_channel_is_refused_like_torch_batchnorm():
+    """a 1 x 1 x 32 x 32 clip leaves layer4 one value per channel: nn.BatchNorm3d (the reference's layers) raises in
+    training mode and computes in eval mode; so does the product"""
+    from helpers import make_config
+    from models.model import create_model
+    m = create_model(make_config(18, 101), is_train=True).cuda()
+    x = torch.randn(1, 3, 1, 32, 32).cuda()
+    m.train()
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        m(x)
+    m.eval()
+    with torch.no_grad():
+        _, lo, _ = m(x)
+    assert bool(torch.isfinite(lo).all())
+    m.train()  # the refused step left the engine usable
+    _, lo, _ = m(torch.randn(2, 3, 4, 32, 32).cuda())
+    lo.sum().backward()
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
 def test_packed_uint8_clips_give_the_float_path_logits():
     """the model takes ops.clip_pack_u8's PackedClips in place of the float clip tensor: same logits as feeding the
     torch-normalised float clip (both round the same values to bf16; <= 1 ulp differences in a handful of inputs)."""

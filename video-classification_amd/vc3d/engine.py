@@ -336,6 +336,10 @@ class R3DEngine:
         stats = stats_pool.take(cb.Co) if training else None
         To, Ho, Wo = d.out_dims()
         count = d.N * To * Ho * Wo
+        if training and count <= 1:
+            # nn.BatchNorm3d's own refusal (torch.nn.functional.batch_norm), same type and text: the reference raises it
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                             % (torch.Size([d.N, cb.Co, To, Ho, Wo]),))
         if training and FUSED_BN_FIN and self.first_stats and not (cb.shift_valid and cb.shift is not None
                                                                      and cb.shift.device == x.device):
             y = ops.conv3d_fwd(d, x, wf)
@@ -351,6 +355,11 @@ class R3DEngine:
             return self._forward(x, training, save)
         except Vc3dError:
             self._reset_tickets()
+            raise
+        except ValueError:  # BatchNorm's one-value refusal: the layers before it have run, as in torch
+            if self._nbt:
+                torch._foreach_add_(self._nbt, 1)
+                self._nbt = []
             raise
 
     def backward(self, saved, dfeat):
