@@ -80,6 +80,11 @@ def test_r3d18_small_clip():
     _check(_run_pair(18, 101, n=4, t=8, hw=64), tol_logit=5e-2)
 
 
+def test_r3d18_odd_crop_gradients():
+    """33 x 33 crops (the engine adds a zero row and column): logits, loss, every gradient and the running statistics"""
+    _check(_run_pair(18, 101, n=4, t=5, hw=33), tol_logit=5e-2)
+
+
 def test_r3d18_full_clip_16x112x112():
     _check(_run_pair(18, 101, n=2, t=16, hw=112))
 
@@ -176,9 +181,11 @@ def test_cpu_input_raises():
         prod(torch.zeros(1, 3, 4, 32, 32))
 
 
-@pytest.mark.parametrize("n,t,h,w", [(1, 3, 34, 50), (2, 7, 98, 130), (5, 2, 66, 34), (7, 4, 48, 80), (1, 16, 112, 112)])
+@pytest.mark.parametrize("n,t,h,w", [(1, 3, 34, 50), (2, 7, 98, 130), (5, 2, 66, 34), (7, 4, 48, 80), (1, 16, 112, 112),
+                                     (2, 5, 33, 47), (3, 4, 65, 64)])
 def test_unusual_clip_shapes(n, t, h, w):
-    """one clip, odd frame counts, non-square and not-multiple-of-16 crops (ragged tiles in every kernel): a training step
+    """one clip, odd frame counts, non-square, not-multiple-of-16 and odd crops (ragged tiles in every kernel; an odd
+    extent gets a zero row / column, which the reference's padded conv sees there as well): a training step
     and the eval-mode logits against the oracle (tests/shape_sweep.py: measured <= 3.5e-2 / 2.1e-2)"""
     from oracle.r3d_torch import synthetic_batch
     oracle, prod, _ = build_pair(18, 101)

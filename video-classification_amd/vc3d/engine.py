@@ -397,6 +397,11 @@ class R3DEngine:
         if not packed:
             if x.dtype not in (F32, BF16):
                 x = x.float()
+            if x.shape[3] % 2 or x.shape[4] % 2:
+                # the stem's space-to-depth source wants even extents; a zero row / column at the far edge is what the
+                # reference's padding-3 conv sees there anyway, and the output extents are the same (one extra copy, for
+                # odd crops only)
+                x = torch.nn.functional.pad(x, (0, x.shape[4] % 2, 0, x.shape[3] % 2))
             x = x.contiguous()
         N, _, T, H, W = x.shape
         dev = x.device
