@@ -174,6 +174,17 @@ def test_grad_accumulation_and_zero_grad():
             assert rel_l2(p.grad, g1[n]) <= 2e-2, n
 
 
+def test_clip_gradient_is_refused_loudly():
+    from vc3d.capi import Vc3dError
+    _, prod, _ = build_pair(18, 101)
+    prod.train()
+    x = torch.randn(2, 3, 4, 32, 32, device="cuda", requires_grad=True)
+    with pytest.raises(Vc3dError, match="input clip"):
+        prod(x)
+    with torch.no_grad():  # no graph: fine
+        prod(x)
+
+
 def test_cpu_input_raises():
     from vc3d.capi import Vc3dError
     _, prod, _ = build_pair(18, 101)

@@ -36,6 +36,11 @@ def backbone_apply(engine, x, training):
     if engine.flat_grad is None or engine.flat_grad.device != params[0].device:
         engine.setup_grads(extra_first=getattr(engine, "head_params", ()))
     need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    if torch.is_grad_enabled() and getattr(x, "requires_grad", False):
+        # the stem has no data-gradient kernel (training never needs d loss / d clip): refuse rather than hand back None
+        from .capi import Vc3dError
+        raise Vc3dError("the vc3d backbone does not compute the gradient with respect to the input clip "
+                        "(pass the clip without requires_grad)")
     return _BackboneFn.apply(x, engine, training, need_grad, *params)
 
 
