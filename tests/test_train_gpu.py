@@ -252,6 +252,56 @@ def test_eval_after_training_uses_current_batchnorm_parameters():
     assert rel_l2(e2, ef) <= 1e-3
 
 
+def test_weight_edits_through_param_data_need_invalidate_weights():
+    """``param.data`` has a version counter of its own, so the packed-operand caches cannot see an edit made through it;
+    engine.invalidate_weights() is the documented way to tell them.  After it the eval logits equal those of a fresh
+    model loaded from the state_dict, with and without the fused optimizer's flat shadow in place; a training step
+    afterwards runs on the edited weights too."""
+    from helpers import rel_l2
+    from models.model import create_model
+    from utils.utils import create_optimizer
+    torch.manual_seed(0)
+    cfg = make_config(18, 5, OPTIMIZER="sgd", LR=0.05, MOMENTUM=0.9)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 3, 4, 32, 32, generator=g).cuda()
+    y = torch.randint(0, 5, (4,), generator=g).cuda()
+
+    def evaluate(m):
+        m.eval()
+        with torch.no_grad():
+            return m(x)[1].float().clone()
+
+    for with_optimizer in (False, True):
+        model = create_model(cfg, True).cuda()
+        if with_optimizer:
+            opt = create_optimizer(cfg, model)
+            model.train()
+            _, score, _ = model(x)
+            opt.zero_grad()
+            F.cross_entropy(score, y).backward()
+            opt.step()
+        e0 = evaluate(model)
+        for m in model.modules():
+            if isinstance(m, (torch.nn.Conv3d, torch.nn.BatchNorm3d)):
+                m.weight.data.mul_(0.7)
+        model.backbone.engine.invalidate_weights()
+        e1 = evaluate(model)
+        fresh = create_model(cfg, False).cuda()
+        fresh.load_state_dict(model.state_dict())
+        ef = evaluate(fresh)
+        assert rel_l2(e1, e0) > 1e-2, "the edit was expected to move the logits"
+        assert rel_l2(e1, ef) <= 1e-3, (with_optimizer, rel_l2(e1, ef))
+        if with_optimizer:
+            model.train()
+            _, score, _ = model(x)
+            opt.zero_grad()
+            F.cross_entropy(score, y).backward()
+            opt.step()
+            fresh2 = create_model(cfg, False).cuda()
+            fresh2.load_state_dict(model.state_dict())
+            assert rel_l2(evaluate(model), evaluate(fresh2)) <= 1e-3
+
+
 def test_training_trajectory_tracks_the_fp32_oracle():
     """Is bf16 storage + bf16 MFMA "good enough" for training?  Same initial weights, same fixed batch, same SGD
     (momentum 0.9): the product path on the GPU and the fp32 torch oracle on the CPU are trained side by side for 16

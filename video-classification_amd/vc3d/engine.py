@@ -201,6 +201,21 @@ class R3DEngine:
             cb.wver = cb.conv.weight._version
         self.param_epoch += 1
 
+    def invalidate_weights(self):
+        """forget every cached operand made from the parameters (packed bf16 conv weights, eval-mode BatchNorm
+        scale / shift).  The caches follow the parameters' tensor versions, which writes through ``param.data`` do not
+        move (``param.data`` carries a version counter of its own): code that edits weights that way -- an EMA copy, a
+        clamp -- calls this afterwards.  ``with torch.no_grad(): param.mul_(...)``, ``load_state_dict`` and the
+        optimizers need nothing."""
+        for cb in self.all_convbn():
+            cb.wver = -1
+            cb.eval_params = None
+        self.stem_wver = -1
+        self.param_epoch += 1
+        if self.flat_shadow is not None:  # the fused optimizers' shadow and dgrad operands: rebuilt from the master
+            ops.shadow_bf16(self.flat_param, self.flat_shadow)
+            self.refresh_packed_weights()
+
     def _bind_grads(self):
         """point every param.grad at its flat view (keeping accumulated values)."""
         if self.flat_grad is None or self.flat_grad.device != self.plist[0].device:
