@@ -252,6 +252,39 @@ def test_eval_after_training_uses_current_batchnorm_parameters():
     assert rel_l2(e2, ef) <= 1e-3
 
 
+def test_partly_frozen_model_trains_like_torch():
+    """layer1 and the stem frozen (requires_grad False): create_optimizer hands back torch.optim.SGD, as the reference
+    does, the frozen parameters keep grad None and do not move (weight decay included), the others do"""
+    from models.model import create_model
+    from utils.utils import create_optimizer
+    torch.manual_seed(0)
+    cfg = make_config(18, 5, OPTIMIZER="sgd", LR=0.05, MOMENTUM=0.9, WD=1e-2)
+    model = create_model(cfg, True).cuda()
+    frozen = [p for n, p in model.named_parameters() if n.startswith(("backbone.conv1", "backbone.bn1", "backbone.layer1"))]
+    assert frozen
+    for p in frozen:
+        p.requires_grad_(False)
+    opt = create_optimizer(cfg, model)
+    assert type(opt) is torch.optim.SGD
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 4, 32, 32, generator=g).cuda()
+    y = torch.randint(0, 5, (4,), generator=g).cuda()
+    model.train()
+    for _ in range(2):
+        _, score, _ = model(x)
+        opt.zero_grad()
+        F.cross_entropy(score, y).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    fz = {id(p) for p in frozen}
+    for n, p in model.named_parameters():
+        if id(p) in fz:
+            assert p.grad is None and torch.equal(p.detach(), before[n]), n
+        else:
+            assert p.grad is not None and not torch.equal(p.detach(), before[n]), n
+
+
 def test_weight_edits_through_param_data_need_invalidate_weights():
     """``param.data`` has a version counter of its own, so the packed-operand caches cannot see an edit made through it;
     engine.invalidate_weights() is the documented way to tell them.  After it the eval logits equal those of a fresh

@@ -29,7 +29,7 @@ def _fusable(model):
     core = model.module if hasattr(model, "module") else model
     return (hasattr(core, "backbone") and hasattr(core.backbone, "engine") and hasattr(core, "clf_haed")
             and not getattr(core, "use_lstm", False)  # the LSTM / actor / critic parameters live outside the flat buffer
-            and all(p.is_cuda for p in core.parameters()))
+            and all(p.is_cuda and p.requires_grad for p in core.parameters()))  # frozen parameters: torch skips them
 
 
 class AverageMeter(object):

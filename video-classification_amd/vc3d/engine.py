@@ -231,6 +231,10 @@ class R3DEngine:
             self.flat_grad.zero_()
         for p in self.plist:
             v = self.grad_views[id(p)]
+            if not p.requires_grad:
+                # a frozen parameter keeps grad None, as under torch autograd: the torch optimizers (what create_optimizer
+                # returns for a partly frozen model) then skip it.  Its slice of the flat buffer is still written.
+                continue
             if p.grad is None:
                 if not fresh:
                     v.zero_()
