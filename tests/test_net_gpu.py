@@ -185,6 +185,22 @@ def test_clip_gradient_is_refused_loudly():
         prod(x)
 
 
+def test_eval_mode_with_gradients_on():
+    """inference without torch.no_grad() works as in the reference (same logits as under no_grad); a backward through
+    eval-mode BatchNorm, which the kernels do not implement, is refused when it is asked for -- not answered with the
+    training-mode formula"""
+    from vc3d.capi import Vc3dError
+    _, prod, _ = build_pair(18, 101)
+    x = torch.randn(2, 3, 4, 32, 32, device="cuda")
+    prod.eval()
+    with torch.no_grad():
+        ref = prod(x)[1].clone()
+    _, lo, _ = prod(x)
+    assert torch.equal(lo.detach(), ref)
+    with pytest.raises(Vc3dError, match="eval-mode BatchNorm"):
+        lo.sum().backward()
+
+
 def test_cpu_input_raises():
     from vc3d.capi import Vc3dError
     _, prod, _ = build_pair(18, 101)

@@ -14,15 +14,22 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, engine, training, anchor, *params):
         # `anchor` = whether activations must be kept (grad mode is off inside Function.forward)
-        feat, saved = engine.forward(x, training, save=bool(anchor))
+        # eval mode with gradients on (inference without torch.no_grad()): nothing is kept -- the backward kernels
+        # implement training-mode BatchNorm only, and a backward through this node says so (below)
+        feat, saved = engine.forward(x, training, save=bool(anchor) and bool(training))
         ctx.engine = engine
-        ctx.saved = saved
+        ctx.saved = saved if training else None
+        ctx.eval_mode = not training
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
         eng = ctx.engine
         if ctx.saved is None:
+            if getattr(ctx, "eval_mode", False):
+                from .capi import Vc3dError
+                raise Vc3dError("backward through eval-mode BatchNorm (running statistics) is not implemented: "
+                                "call model.train() for the training step")
             raise RuntimeError("backbone forward ran without saving activations")
         eng._bind_grads()
         eng.backward(ctx.saved, dfeat)
