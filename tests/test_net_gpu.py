@@ -201,6 +201,17 @@ def test_eval_mode_with_gradients_on():
         lo.sum().backward()
 
 
+def test_mixed_batchnorm_modes_are_refused():
+    from vc3d.capi import Vc3dError
+    _, prod, _ = build_pair(18, 101)
+    prod.train()
+    prod.backbone.layer2[0].bn1.eval()
+    with pytest.raises(Vc3dError, match="different train / eval mode"):
+        prod(torch.randn(2, 3, 4, 32, 32, device="cuda"))
+    prod.train()
+    prod(torch.randn(2, 3, 4, 32, 32, device="cuda"))
+
+
 def test_cpu_input_raises():
     from vc3d.capi import Vc3dError
     _, prod, _ = build_pair(18, 101)

@@ -424,6 +424,10 @@ class R3DEngine:
             x = x.contiguous()
         N, _, T, H, W = x.shape
         dev = x.device
+        if any(cb.bn.training != training for cb in self.all_convbn()):
+            # e.g. bn.eval() on some layers of a model in train(): one mode per step is what the kernels implement
+            raise Vc3dError("BatchNorm layers in a different train / eval mode than the backbone are not supported "
+                            "(the engine runs every BatchNorm in the backbone's mode)")
         self._nbt = []
         if training:
             self.stat_epoch += 1
