@@ -371,6 +371,9 @@ class R3DEngine:
 
     def forward(self, x, training, save):
         try:
+            if x.is_cuda and x.device.index != torch.cuda.current_device():
+                with torch.cuda.device(x.device):  # launches go to the current device's stream: make it the clips' device
+                    return self._forward(x, training, save)
             return self._forward(x, training, save)
         except Vc3dError:
             self._reset_tickets()
@@ -424,6 +427,12 @@ class R3DEngine:
             x = x.contiguous()
         N, _, T, H, W = x.shape
         dev = x.device
+        if dev != self.stem.conv.weight.device:
+            # what a torch.nn.DataParallel replica would do: its parameters are copies on another GPU, the engine belongs
+            # to the original module.  One process per GPU (vc3d.ddp.DataParallel3D) is the supported way to use several.
+            raise Vc3dError("clips on %s but the backbone's parameters on %s: move both to one GPU (for several GPUs run "
+                            "one process per GPU with DataParallel3D; torch.nn.DataParallel replicas are not supported)"
+                            % (dev, self.stem.conv.weight.device))
         if any(cb.bn.training != training for cb in self.all_convbn()):
             # e.g. bn.eval() on some layers of a model in train(): one mode per step is what the kernels implement
             raise Vc3dError("BatchNorm layers in a different train / eval mode than the backbone are not supported "
