@@ -185,20 +185,50 @@ def test_clip_gradient_is_refused_loudly():
         prod(x)
 
 
-def test_eval_mode_with_gradients_on():
-    """inference without torch.no_grad() works as in the reference (same logits as under no_grad); a backward through
-    eval-mode BatchNorm, which the kernels do not implement, is refused when it is asked for -- not answered with the
-    training-mode formula"""
-    from vc3d.capi import Vc3dError
-    _, prod, _ = build_pair(18, 101)
-    x = torch.randn(2, 3, 4, 32, 32, device="cuda")
-    prod.eval()
-    with torch.no_grad():
-        ref = prod(x)[1].clone()
-    _, lo, _ = prod(x)
-    assert torch.equal(lo.detach(), ref)
-    with pytest.raises(Vc3dError, match="eval-mode BatchNorm"):
-        lo.sum().backward()
+def test_eval_mode_backward_with_frozen_batchnorm_statistics():
+    """model.eval() with gradients on -- fine-tuning with frozen BatchNorm statistics: the forward normalises with the
+    running statistics (which must not move), the backward has no batch-mean terms (dy = scale * g) and still makes
+    dgamma / dbeta.  Against torch autograd on the oracle in eval mode; the logits equal the no_grad inference path's
+    up to the rounding points (that path rounds once, after BatchNorm; this one keeps the conv output in bf16)."""
+    from oracle.r3d_torch import synthetic_batch
+    # R3D-50 at random initialisation is the noisy case (eval logits ~12 % from fp32, gradients ~50 %, norms within 13 %:
+    # bf16 storage through 50 unnormalised layers); it is here for the Bottleneck plumbing, R3D-18 carries the tight bars
+    for depth, tol_lo, tol_g, tol_cos, tol_n in ((18, 5e-2, 0.25, 0.95, 0.10), (50, 0.15, 0.70, 0.75, 0.20)):
+        oracle, prod, _ = build_pair(depth, 101)
+        x, y = synthetic_batch(4, 4, 64, 64, 101, 21)
+        oracle.train()
+        prod.train()
+        with torch.no_grad():  # one training step's worth of running statistics
+            oracle(x)
+            prod(x.cuda())
+        oracle.eval()
+        prod.eval()
+        rs0 = {n: b.clone() for n, b in prod.named_buffers()}
+        lo_ref = oracle(x)
+        F.cross_entropy(lo_ref, y).backward()
+        _, lo, _ = prod(x.cuda())
+        F.cross_entropy(lo, y.cuda()).backward()
+        torch.cuda.synchronize()
+        assert rel_l2(lo.detach(), lo_ref.detach()) <= tol_lo
+        with torch.no_grad():
+            assert rel_l2(prod(x.cuda())[1], lo.detach()) <= tol_lo
+        for n, b in prod.named_buffers():
+            assert torch.equal(b, rs0[n]), n  # eval mode: no running-statistics update, no step count
+        g_ref = {n: p.grad for n, p in oracle.named_parameters()}
+        # The formula itself is pinned per layer at bf16 tolerance (test_ops_gpu: ...frozen_statistics); here the plumbing:
+        # bf16 rounding accumulates along the backward chain (R3D-18: 1 % at the head, ~15 % at the stem, measured), a
+        # wrong term anywhere moves a whole layer's gradient norm, so the norms are held to a few percent
+        worst_ratio = 0.0
+        for n, p in prod.named_parameters():
+            r = g_ref[n.replace("clf_haed.", "clf_head.")]
+            worst_ratio = max(worst_ratio, abs(float(p.grad.float().norm().cpu() / r.norm()) - 1.0))
+        a = torch.cat([p.grad.flatten().float().cpu() for _, p in prod.named_parameters()]).double()
+        b = torch.cat([g_ref[n.replace("clf_haed.", "clf_head.")].flatten() for n, _ in prod.named_parameters()]).double()
+        e_all = float((a - b).norm() / b.norm())
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        print("R3D-%d frozen-statistics backward: all-gradient rel-L2 %.3e cos %.4f, worst norm deviation %.3e"
+              % (depth, e_all, cos, worst_ratio))
+        assert e_all <= tol_g and cos >= tol_cos and worst_ratio <= tol_n
 
 
 def test_mixed_batchnorm_modes_are_refused():

@@ -383,6 +383,49 @@ def test_shape_errors_are_loud():
         ops.bn_apply(torch.zeros(8, 64), torch.zeros(4, 64), 64)  # CPU tensors: no fallback
 
 
+@pytest.mark.parametrize("C,shape", [(64, (2, 4, 6, 6)), (256, (3, 2, 5, 5))])
+@pytest.mark.parametrize("mode", ["plain", "relu"])
+def test_batchnorm_backward_with_frozen_statistics(C, shape, mode):
+    """eval-mode BatchNorm (running statistics) has no batch-mean terms in its backward: dy = gamma * invstd * g, dgamma
+    and dbeta as in training mode but with the running statistics in x_hat.  ops.bn_bwd(frozen=True) against torch
+    autograd on nn.BatchNorm3d.eval(), with and without the fused finalize."""
+    _need_gpu()
+    from vc3d import ops
+    N, T, H, W = shape
+    g = torch.Generator().manual_seed(3 * C + N)
+    y = bf16_round(torch.randn(N, C, T, H, W, generator=g) * 2 + 0.5)
+    y.requires_grad_(True)
+    bn = torch.nn.BatchNorm3d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.3 + 0.4)
+        bn.running_var.copy_(torch.rand(C, generator=g) * 3 + 0.5)
+    bn.eval()
+    z_ref = bn(y)
+    if mode == "relu":
+        z_ref = torch.relu(z_ref)
+    dz = bf16_round(torch.randn(z_ref.shape, generator=g))
+    z_ref.backward(dz)
+    yd = to_nthwc_dev(y.detach())
+    params = ops.bn_eval_params(bn.weight.detach().cuda(), bn.bias.detach().cuda(), bn.running_mean.cuda(),
+                                bn.running_var.cuda(), bn.eps)
+    z = ops.bn_apply(yd, params, C, relu=(mode == "relu"))
+    assert rel_l2(from_nthwc(z), z_ref.detach()) <= TOL_BF16
+    for ticket in (None, torch.zeros(64, dtype=torch.int32, device="cuda")):
+        dgamma, dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dy, _ = ops.bn_bwd(yd, to_nthwc_dev(dz), params, C, dgamma, dbeta, mask=2 if mode == "relu" else 0, ticket=ticket,
+                           frozen=True)
+        torch.cuda.synchronize()
+        assert rel_l2(from_nthwc(dy), y.grad) <= TOL_BF16
+        assert rel_l2(dgamma.cpu(), bn.weight.grad) <= 5e-3
+        assert rel_l2(dbeta.cpu(), bn.bias.grad) <= 5e-3
+        # and it is not the training-mode formula (which subtracts the batch means of g and g * x_hat)
+        dg2, db2 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dy_train, _ = ops.bn_bwd(yd, to_nthwc_dev(dz), params, C, dg2, db2, mask=2 if mode == "relu" else 0)
+        assert rel_l2(from_nthwc(dy_train), y.grad) > 5e-2
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 4, 8, 8), (1, 64, 5, 7, 9), (2, 128, 1, 6, 6)])
 def test_bn_bwd_through_pool_matches_unfused(shape):
     """stem backward: BN+ReLU backward fed by a gather from the pooled gradient == max-pool backward

@@ -14,22 +14,17 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, engine, training, anchor, *params):
         # `anchor` = whether activations must be kept (grad mode is off inside Function.forward)
-        # eval mode with gradients on (inference without torch.no_grad()): nothing is kept -- the backward kernels
-        # implement training-mode BatchNorm only, and a backward through this node says so (below)
-        feat, saved = engine.forward(x, training, save=bool(anchor) and bool(training))
+        # (eval mode with gradients on keeps the activations too: a backward then runs with frozen BatchNorm statistics,
+        # engine._backward; plain inference belongs under torch.no_grad(), which takes the fused inference epilogues)
+        feat, saved = engine.forward(x, training, save=bool(anchor))
         ctx.engine = engine
-        ctx.saved = saved if training else None
-        ctx.eval_mode = not training
+        ctx.saved = saved
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
         eng = ctx.engine
         if ctx.saved is None:
-            if getattr(ctx, "eval_mode", False):
-                from .capi import Vc3dError
-                raise Vc3dError("backward through eval-mode BatchNorm (running statistics) is not implemented: "
-                                "call model.train() for the training step")
             raise RuntimeError("backbone forward ran without saving activations")
         eng._bind_grads()
         eng.backward(ctx.saved, dfeat)

@@ -461,7 +461,7 @@ class R3DEngine:
         pd = ops.pool_desc(N, st.Co, T, H // 2, W // 2, pk, ps, pp)
         a0, idx = ops.maxpool3d_fwd(pd, y0, p0)
         self._t("conv1", clip=x, y=y0, prm=p0, pooled=a0)
-        saved = {"stem": (xs, y0, p0, pd, idx, a0, (N, T, H, W)), "blocks": []} if save else None
+        saved = {"stem": (xs, y0, p0, pd, idx, a0, (N, T, H, W)), "blocks": [], "training": training} if save else None
         if not save:
             del xs, y0, idx
         cur = a0
@@ -527,6 +527,8 @@ class R3DEngine:
         g = ops.gavgpool_bwd(dfeat.contiguous(), N, To * Ho * Wo, Cf, shape)
         self._t("final", dfeat=dfeat, dx=g)
         order = list(zip(reversed(self.blocks), reversed(saved["blocks"])))
+        # eval-mode forward (running statistics: fine-tuning with frozen BatchNorm statistics): plain reductions, no folds
+        frozen = not saved.get("training", True)
         coef = None  # of this block's last BN, when its reduction came with the dgrad that completed g
         for bi, ((cbs, ds), (xin, recs, dsrec)) in enumerate(order):
             # last conv of the block: BN + residual + ReLU
@@ -535,17 +537,17 @@ class R3DEngine:
             # identity shortcut into a pointwise first conv: the masked copy of g (gres) is not made -- that conv's data
             # gradient accumulates onto g itself and applies the ReLU bits to it on the way (vc_conv3d_dgrad_fused)
             d0 = recs[0][0]
-            masked_acc = (FOLD_BN_RED and self.trace is None and ds is None and out.dtype == torch.uint8 and
+            masked_acc = (FOLD_BN_RED and not frozen and self.trace is None and ds is None and out.dtype == torch.uint8 and
                           d0.kt * d0.kh * d0.kw == 1 and d0.st * d0.sh * d0.sw == 1)
             dy, gres = ops.bn_bwd(y, g, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias),
                                   mask=3 if out.dtype == torch.uint8 else 1, aux=out, want_g=not masked_acc,
                                   sums=sums_pool.take(cb.Co) if coef is None else None, ticket=self._bticket(cb),
-                                  coef=coef, reduced=coef is not None)
+                                  coef=coef, reduced=coef is not None, frozen=frozen)
             coef = None
             self._ready(cb.bn.weight, cb.bn.bias)
             self._wgrad(d, h, dy, cb.conv)
             _, wd = cb.weights()
-            fold = FOLD_BN_RED and FUSED_BN_FIN and self.trace is None
+            fold = FOLD_BN_RED and FUSED_BN_FIN and self.trace is None and not frozen
 
             def red_of(pcb, py, pprm, bits):
                 """the reduction of pcb's BatchNorm backward, to ride along with the dgrad that makes its gradient"""
@@ -565,14 +567,14 @@ class R3DEngine:
                 # the forward's own expression) instead of reading the activation z a third tensor per pass
                 dy, _ = ops.bn_bwd(y, dz, prm, cb.Co, self.gview(cb.bn.weight), self.gview(cb.bn.bias), mask=2,
                                    sums=sums_pool.take(cb.Co) if icoef is None else None, ticket=self._bticket(cb),
-                                   coef=icoef, reduced=icoef is not None)
+                                   coef=icoef, reduced=icoef is not None, frozen=frozen)
                 icoef = None
                 self._ready(cb.bn.weight, cb.bn.bias)
                 if i == 0 and ds is not None:
                     # downsample branch first so the first conv's dgrad can accumulate onto it
                     dd, yd, prmd = dsrec
                     dyd, _ = ops.bn_bwd(yd, gres, prmd, ds.Co, self.gview(ds.bn.weight), self.gview(ds.bn.bias),
-                                        mask=0, sums=sums_pool.take(ds.Co), ticket=self._bticket(ds))
+                                        mask=0, sums=sums_pool.take(ds.Co), ticket=self._bticket(ds), frozen=frozen)
                     self._ready(ds.bn.weight, ds.bn.bias)
                     self._wgrad(dd, xin, dyd, ds.conv)
                     _, wdd = ds.weights()
@@ -612,10 +614,11 @@ class R3DEngine:
             self._t("conv1", dpooled=g, dz=din)
         if all(k <= 2 * s for k, s in zip(self.pool[0], self.pool[1])):
             dy0 = ops.bn_bwd_pooled(pd, y0, g, idx, p0, st.Co, self.gview(st.bn.weight), self.gview(st.bn.bias),
-                                    sums=sums_pool.take(st.Co), pooled=a0, ticket=self._bticket(st))
+                                    sums=sums_pool.take(st.Co), pooled=a0, ticket=self._bticket(st), frozen=frozen)
         else:  # windows overlapping more than twice per axis: materialise the pool-input gradient
             dy0, _ = ops.bn_bwd(y0, ops.maxpool3d_bwd(pd, g, idx), p0, st.Co, self.gview(st.bn.weight),
-                                self.gview(st.bn.bias), mask=2, sums=sums_pool.take(st.Co), ticket=self._bticket(st))
+                                self.gview(st.bn.bias), mask=2, sums=sums_pool.take(st.Co), ticket=self._bticket(st),
+                                frozen=frozen)
         self._ready(st.bn.weight, st.bn.bias)
         if self._stem_scratch is None or self._stem_scratch.device != dev or self._stem_scratch.shape[0] != st.Co:
             self._stem_scratch = torch.zeros(st.Co, ops.STEM_K, dtype=F32, device=dev)

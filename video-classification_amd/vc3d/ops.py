@@ -422,8 +422,11 @@ def bn_apply(y, params, C, residual=None, relu=True, out=None, relu_bits=None):
 
 
 def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=False, sums=None, coef=None,
-           dy=None, g_out=None, ticket=None, reduced=False):
+           dy=None, g_out=None, ticket=None, reduced=False, frozen=False):
     """BatchNorm backward (batch statistics).  Returns (dy, g) with g = masked dz or None.
+    `frozen`: the forward normalised with the running statistics (eval mode), which do not depend on the batch: the
+    mean terms of the backward vanish, dy = scale * g.  The reduction still makes dgamma / dbeta; its coef is zeroed
+    before the apply pass (one small fill: this is the fine-tuning-with-frozen-statistics path, not the hot one).
     `ticket` (capi.VC_TICKET_WORDS zero int32 words): the reduction's last workgroup does the finalize (one launch less).
     `reduced`: coef, dgamma and dbeta are already there (conv3d_dgrad's bnred made them with dz); only the apply pass runs."""
     n = y.numel()
@@ -464,12 +467,17 @@ def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=Fal
               "vc_bn_bwd_reduce")
         check(lib.vc_bn_bwd_finalize(ptr(sums), C, float(rows), ptr(coef), ptr(gamma_grad), ptr(beta_grad), s),
               "vc_bn_bwd_finalize")
+    if frozen:
+        if reduced:
+            raise capi.Vc3dError("bn_bwd: frozen statistics and a folded reduction do not go together")
+        coef.zero_()
     check(lib.vc_bn_bwd_apply(ptr(y), ptr(dz), ptr(aux), ptr(params), ptr(coef), ptr(dy), ptr(g_out), n, C, mask, s),
           "vc_bn_bwd_apply")
     return dy, g_out
 
 
-def bn_bwd_pooled(pd, y, dpooled, idx, params, C, gamma_grad, beta_grad, sums=None, pooled=None, ticket=None):
+def bn_bwd_pooled(pd, y, dpooled, idx, params, C, gamma_grad, beta_grad, sums=None, pooled=None, ticket=None,
+                  frozen=False):
     """BN+ReLU backward of the stem straight from the max-pool output gradient (no materialised
     pool-input gradient).  Returns dy (gradient of the conv output).  `pooled` = the pool's output
     (maxpool3d_fwd with the same params): lets the reduction skip its element-wise gather of y."""
@@ -500,6 +508,8 @@ def bn_bwd_pooled(pd, y, dpooled, idx, params, C, gamma_grad, beta_grad, sums=No
               "vc_bn_bwd_reduce_pooled")
         check(lib.vc_bn_bwd_finalize(ptr(sums), C, float(n // C), ptr(coef), ptr(gamma_grad), ptr(beta_grad), s),
               "vc_bn_bwd_finalize")
+    if frozen:  # see bn_bwd
+        coef.zero_()
     check(lib.vc_bn_bwd_apply_pooled(pd, ptr(y), ptr(dpooled), ptr(idx), ptr(params), ptr(coef), ptr(dy), s),
           "vc_bn_bwd_apply_pooled")
     return dy
