@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: train clips/sec of the 3D-ResNet at 16x112x112 on N MI355X GPUs.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: when the command is not already a rank of a torch.distributed.run launch (WORLD_SIZE unset), bench.py itself
+starts N rank processes, one per GPU (video-classification_amd/launch.py: fresh children, before this process touches
+the GPU), relays rank 0's JSON line and exits with the ranks' status -- the counterpart of the reference fanning out
+over config.GPUS inside one command (/root/reference/train.py:42-43,65).  Under torch.distributed.run it is one rank.
+`n_gpus` in the line is the world size the process group reports; a mismatch with --gpus is an error, not a warning.
 
 A step = forward + cross-entropy + backward + optimizer step on one synthetic batch that is
 already resident in HBM.  Rank 0 prints ONE JSON line (contract in the task statement) with
@@ -31,9 +37,8 @@ for p in (ROOT, PKG, os.path.join(PKG, "lib")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
+import launch  # noqa: E402  (stdlib only: no torch, no HIP)
+
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (guide: ~2.5 PF dense)
 PEAK_HBM_GBS = 8000.0
@@ -58,6 +63,11 @@ def parse():
     ap.add_argument("--profile-kernels", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--eval", action="store_true", help="forward-only (valid.py path) throughput")
     ap.add_argument("--optimizer", default="sgd", choices=("sgd", "adam"), help="TRAIN.OPTIMIZER (reference default: adam)")
+    ap.add_argument("--views", type=int, default=0,
+                    help="with --eval: BASELINE config 5's protocol -- every video is VIEWS clips (10 clips x 3 crops = 30) "
+                         "through valid.py's loader and validate(), logits averaged per video; --batch = clips per forward")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the rank processes, have each report its environment and stop before touching the GPU")
     return ap.parse_args()
 
 
@@ -171,9 +181,27 @@ def family_rooflines(table):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not launch.launched() and (args.gpus > 1 or args.dry_launch):
+        # one command, N GPUs: N fresh rank processes; this parent never initialises HIP
+        raise SystemExit(launch.fan_out(os.path.abspath(__file__), sys.argv[1:], args.gpus, dry=args.dry_launch))
+    if os.environ.get(launch.DRY_ENV) == "1":
+        rec = launch.dry_child_report()
+        if rec["RANK"] == "0":
+            print(json.dumps({"dry_launch": True, "n_gpus": int(rec["WORLD_SIZE"]), "gpus_requested": args.gpus}), flush=True)
+        return
+    global torch, dist, F
+    import torch
+    import torch.distributed as dist
+    import torch.nn.functional as F
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = launch.local_device_index()
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launch has WORLD_SIZE %d; refusing to report a line for the wrong "
+                         "job size (run `python bench.py --gpus %d` by itself, or torch.distributed.run with "
+                         "--nproc-per-node %d)" % (args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -185,8 +213,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     if args.model is None:
         args.model = 18 if world == 1 else 50
-    if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if ddp and dist.get_world_size() != world:
+        raise SystemExit("bench.py: the process group has %d ranks, WORLD_SIZE says %d" % (dist.get_world_size(), world))
 
     import vc3d
     from vc3d import ops

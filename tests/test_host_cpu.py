@@ -11,6 +11,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -306,3 +307,72 @@ def test_c_abi_host_code_under_sanitizers():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     assert r.stdout.startswith("calls ") and int(r.stdout.split()[1].rstrip(",")) > 5000
+
+
+# ---- one command, N GPUs (reference train.py:42-43,65; valid.py:42-43,55): the launcher, without a GPU
+
+def _dry_children(stderr):
+    import json as _json
+    return sorted((_json.loads(ln.split(" ", 1)[1]) for ln in stderr.splitlines() if ln.startswith("DRY_LAUNCH_CHILD ")),
+                  key=lambda r: int(r["RANK"]))
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_gpus_n_starts_n_rank_processes(n):
+    """`python bench.py --gpus N` by itself (the driver's command form) starts N fresh rank processes with the
+    torch.distributed environment and prints ONE JSON line whose n_gpus is the world size; --dry-launch stops each
+    child before it touches the GPU."""
+    import json as _json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-launch"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kids = _dry_children(r.stderr)
+    assert [int(k["RANK"]) for k in kids] == list(range(n)) and [k["device"] for k in kids] == list(range(n))
+    assert all(k["WORLD_SIZE"] == str(n) and k["MASTER_ADDR"] == "127.0.0.1" for k in kids)
+    assert len({k["MASTER_PORT"] for k in kids}) == 1 and len({k["pid"] for k in kids}) == n
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and _json.loads(lines[0]) == {"dry_launch": True, "n_gpus": n, "gpus_requested": n}
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE 2" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.parametrize("script", ["train.py", "valid.py"])
+def test_config_gpus_fans_out_one_rank_per_listed_device(script):
+    """config.GPUS = '1,3,6' (reference config.py:16, train.py:42): three ranks, rank r on the r-th listed device."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["VC_DRY_LAUNCH_PARENT"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "video-classification_amd", script), "GPUS=1,3,6",
+                        "TRAIN.END_EPOCH=1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kids = _dry_children(r.stderr)
+    assert [k["device"] for k in kids] == [1, 3, 6] and all(k["WORLD_SIZE"] == "3" for k in kids)
+    assert all(k["VC_DEVICE_IDS"] == "1,3,6" for k in kids)
+
+
+def test_launcher_propagates_a_failing_rank_and_stops_the_others(tmp_path):
+    import launch
+    import subprocess
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(7)\n"
+                      "print('rank', os.environ['RANK'], flush=True)\ntime.sleep(60)\n")
+    drv = tmp_path / "drv.py"
+    drv.write_text("import sys\nsys.path.insert(0, %r)\nimport launch\nsys.exit(launch.fan_out(%r, [], 3))\n"
+                   % (os.path.dirname(launch.__file__), str(script)))
+    import time as _time
+    t0 = _time.time()
+    r = subprocess.run([sys.executable, str(drv)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 7 and _time.time() - t0 < 30
+    assert r.stdout.strip() == "rank 0"  # only rank 0's stdout reaches ours
+    with pytest.raises(ValueError):
+        launch.parse_gpus("0,0")
+    assert launch.parse_gpus("0, 2,5") == [0, 2, 5]

@@ -5,10 +5,12 @@ create_optimizer -> MultiStepLR -> loaders -> epoch loop of train() / validate()
 validation accuracy (the reference leaves "save the model" as a TODO at :91; done here).
 
 Data parallelism: the reference wraps the model in torch.nn.DataParallel over config.GPUS
-(:42-43) with a global batch of BATCH_SIZE * len(gpus) (:65).  Here every GPU is its own process
-(launch with `python -m torch.distributed.run --nproc-per-node G train.py`); each rank loads
-BATCH_SIZE clips per step, gradients are averaged with bucketed RCCL all-reduce overlapped with
-backward (vc3d/ddp.py).  A plain `python train.py` runs one GPU.
+(:42-43) with a global batch of BATCH_SIZE * len(gpus) (:65).  Here every GPU is its own process:
+`python train.py GPUS=0,1,2,3` starts one rank per listed device itself (launch.py: fresh children,
+before this process touches the GPU) -- or launch it with `python -m torch.distributed.run
+--nproc-per-node G train.py`.  Each rank loads BATCH_SIZE clips per step, gradients are averaged
+with bucketed RCCL all-reduce overlapped with backward (vc3d/ddp.py).  A plain `python train.py`
+runs the one GPU config.GPUS names ('0').
 
 Overrides: KEY=VALUE pairs on the command line, e.g. TRAIN.END_EPOCH=1 MODEL.RESNET_TYPE=50.
 """
@@ -23,18 +25,24 @@ import os
 import sys
 
 import _init_paths  # noqa: F401
-import torch
-import torch.distributed as dist
-import torch.utils.data
-import torch.utils.data.distributed
-
+import launch
 from core.config import config
-from core.function import train, validate
-from core.loss import Loss
-from dataset.dataset import get_dataset
-from models.model import create_model
-from utils.utils import create_logger, create_optimizer
-from vc3d.ddp import DataParallel3D
+
+
+def _heavy_imports():
+    """torch, the HIP library and the modules built on them: imported only in a process that will use the GPU
+    (the parent of a fan-out never does)."""
+    global torch, dist, train, validate, Loss, get_dataset, create_model, create_logger, create_optimizer, DataParallel3D
+    import torch
+    import torch.distributed as dist
+    import torch.utils.data
+    import torch.utils.data.distributed
+    from core.function import train, validate
+    from core.loss import Loss
+    from dataset.dataset import get_dataset
+    from models.model import create_model
+    from utils.utils import create_logger, create_optimizer
+    from vc3d.ddp import DataParallel3D
 
 
 def apply_overrides(cfg, argv):
@@ -57,14 +65,36 @@ def apply_overrides(cfg, argv):
     return cfg
 
 
-def setup_distributed():
+def fan_out_if_needed(cfg, script, argv):
+    """config.GPUS names several devices (reference train.py:42, valid.py:42) and this process is not yet a rank:
+    start one rank per device and return their exit code; None when this process is to do the work itself."""
+    gpus = launch.parse_gpus(cfg.GPUS)
+    if launch.launched():
+        return None
+    dry = os.environ.get("VC_DRY_LAUNCH_PARENT") == "1"
+    if len(gpus) == 1 and not dry:
+        return None  # a single process drives the one device GPUS names (setup_distributed)
+    return launch.fan_out(script, argv, len(gpus), device_ids=gpus, dry=dry)
+
+
+def setup_distributed(cfg=None):
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    if cfg is not None and world > 1 and launch.DEVICES_ENV in os.environ:
+        n = len(launch.parse_gpus(cfg.GPUS))
+        if n != world:
+            raise SystemExit("config.GPUS=%r names %d devices but WORLD_SIZE is %d" % (cfg.GPUS, n, world))
+    index = launch.local_device_index()
+    if cfg is not None and not launch.launched():
+        index = launch.parse_gpus(cfg.GPUS)[0]
+    if index >= torch.cuda.device_count():
+        raise SystemExit("device %d requested (config.GPUS / LOCAL_RANK) but %d visible" % (index, torch.cuda.device_count()))
+    torch.cuda.set_device(index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    return world, int(os.environ.get("RANK", "0")), torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", index))
+    return world, int(os.environ.get("RANK", "0")), torch.device("cuda", index)
 
 
 def make_loader(cfg, if_train, world, rank, length=None):
@@ -79,8 +109,18 @@ def make_loader(cfg, if_train, world, rank, length=None):
 
 
 def main(argv=None):
-    cfg = apply_overrides(config.clone(), sys.argv[1:] if argv is None else argv)
-    world, rank, dev = setup_distributed()
+    argv = list(sys.argv[1:] if argv is None else argv)
+    cfg = apply_overrides(config.clone(), argv)
+    code = fan_out_if_needed(cfg, os.path.abspath(__file__), argv)
+    if code is not None:
+        if code:
+            raise SystemExit(code)
+        return None
+    if os.environ.get(launch.DRY_ENV) == "1":
+        launch.dry_child_report()
+        return None
+    _heavy_imports()
+    world, rank, dev = setup_distributed(cfg)
     logger = create_logger(cfg, 'train')
     model = create_model(cfg, is_train=True).to(dev)
     net = DataParallel3D(model, bucket_mb=cfg.TRAIN.BUCKET_MB) if world > 1 else model
@@ -122,9 +162,13 @@ def main(argv=None):
                 torch.save({'state_dict': model.state_dict(), 'epoch': epoch, 'perf': best_perf}, path)
                 logger.info('=> saved best model (top-1 %.4f) to %s', best_perf, path)
         if rank == 0:
+            # written beside the old file and renamed over it: a kill during the write leaves the previous epoch's
+            # checkpoint intact.  'engine' (the BatchNorm shifts) is rank 0's: the shifts are per replica, so under
+            # data parallelism a resumed run repeats rank 0 bit for bit and the other ranks to rounding
             torch.save({'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict(),
                         'lr_scheduler': lr_scheduler.state_dict(), 'epoch': epoch, 'best_perf': best_perf,
-                        'engine': model.backbone.engine.state_dict()}, ckpt_path)
+                        'engine': model.backbone.engine.state_dict()}, ckpt_path + '.tmp')
+            os.replace(ckpt_path + '.tmp', ckpt_path)
     if world > 1:
         dist.destroy_process_group()
     return best_perf

@@ -19,17 +19,9 @@ import os
 import sys
 
 import _init_paths  # noqa: F401
-import torch
-import torch.distributed as dist
-import torch.utils.data
-
+import launch
 from core.config import config
-from core.function import validate
-from core.loss import Loss
-from dataset.dataset import MultiViewClips
-from models.model import create_model
-from train import apply_overrides, setup_distributed
-from utils.utils import create_logger
+from train import apply_overrides, fan_out_if_needed, setup_distributed
 
 
 def main(argv=None):
@@ -40,7 +32,24 @@ def main(argv=None):
             ckpt = a[5:]
             argv.remove(a)
     cfg = apply_overrides(config.clone(), argv)
-    world, rank, dev = setup_distributed()
+    # config.GPUS with several devices: one rank per device, as the reference's DataParallel over gpus (valid.py:42-43)
+    code = fan_out_if_needed(cfg, os.path.abspath(__file__), argv + (["CKPT=" + ckpt] if ckpt else []))
+    if code is not None:
+        if code:
+            raise SystemExit(code)
+        return None
+    if os.environ.get(launch.DRY_ENV) == "1":
+        launch.dry_child_report()
+        return None
+    import torch
+    import torch.distributed as dist
+    import torch.utils.data
+    from core.function import validate
+    from core.loss import Loss
+    from dataset.dataset import MultiViewClips
+    from models.model import create_model
+    from utils.utils import create_logger
+    world, rank, dev = setup_distributed(cfg)
     create_logger(cfg, 'valid')
     model = create_model(cfg, is_train=False).to(dev)
     if ckpt:
