@@ -99,7 +99,9 @@ int vc_conv3d_fwd_act(const vc_conv3d_desc* d, const void* x, const void* w, voi
  * bits in y as vc_conv3d_fwd with a workspace of vc_conv3d_workspace_bytes(d, 0).  A geometry whose plan needs more
  * than VC_STATIC_SCRATCH_BYTES is rejected (-3, message in vc_last_error) -- it is never silently run unsplit.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
- * serialise them or use vc_conv3d_fwd.  Nothing is kept between calls (the array needs no clearing). */
+ * serialise them or use vc_conv3d_fwd.  Nothing is kept between calls (the array needs no clearing).
+ * The array's device address is looked up once per device, on the first call there; vc_static_scratch_bytes() with
+ * the device current does that lookup ahead of time -- call it before a stream capture begins. */
 #define VC_STATIC_SCRATCH_BYTES (64u << 20)
 size_t vc_static_scratch_bytes(void);
 int vc_conv3d_fwd_noalloc(const vc_conv3d_desc* d, const void* x, const void* w, void* y,

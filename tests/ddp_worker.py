@@ -26,11 +26,13 @@ from utils.utils import create_optimizer  # noqa: E402
 from vc3d.ddp import DataParallel3D  # noqa: E402
 
 
-def build(lr=0.01):
+def build(lr=0.01, lstm=False):
     cfg = config.clone()
     cfg.MODEL.RESNET_TYPE = 18
     cfg.MODEL.CLFDIM = 11
     cfg.MODEL.INIT_WEIGHTS = False
+    if lstm:
+        cfg.MODEL.USE_LSTM, cfg.MODEL.LSTM_OUTDIM = True, 128
     cfg.TRAIN.OPTIMIZER = "sgd"
     cfg.TRAIN.LR = lr
     torch.manual_seed(3)
@@ -159,10 +161,64 @@ def main_shards():
     dist.destroy_process_group()
 
 
+def main_lstm():
+    """The recurrent head (MODEL.USE_LSTM) under data parallelism: its parameters live outside the engine's flat
+    buffer; after backward every rank must hold the SAME gradients for them, equal to the average of the two shards'
+    own gradients (computed by each rank before the wrapped run, exchanged through gloo)."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, y = batch(16)
+    per = x.shape[0] // world
+    xs, ys = x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
+
+    def step(wrap):
+        cfg, model, crit, opt = build(lstm=True)
+        net = DataParallel3D(model, bucket_mb=4, tail_mb=0.25) if wrap else model
+        assert not wrap or net.grad_dtype == "fp32", "fp32 on the wire is the default"
+        net.train()
+        model.lstm.reset(per)
+        action, score, value = net(xs)
+        g = torch.Generator().manual_seed(9 + rank)
+        log_prob = torch.log(action.clamp_min(1e-6))
+        adv = torch.randn(per, 1, generator=g).cuda() + value
+        loss = crit(score, ys, log_prob, adv)
+        opt.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        extras = net.extra_params() if wrap else DataParallel3D.extra_params(type("W", (), {"module": model})())
+        names = {id(p): n for n, p in model.named_parameters()}
+        return {names[id(p)]: p.grad.detach().float().cpu().clone() for p in extras}, model.backbone.engine.flat_grad.cpu().clone()
+
+    own, own_flat = step(False)
+    got, got_flat = step(True)
+    assert {"lstm.lstm.weight_ih", "lstm.lstm.weight_hh", "act_head.0.weight", "clf_haed.weight", "crit_head.bias"} <= set(got)
+    worst_avg, worst_ranks, self_dev = 0.0, 0.0, 0.0
+    for name in sorted(own):
+        parts = [torch.zeros_like(own[name]) for _ in range(world)]
+        dist.all_gather(parts, own[name])
+        avg = sum(parts) / world
+        theirs = [torch.zeros_like(got[name]) for _ in range(world)]
+        dist.all_gather(theirs, got[name])
+        assert all(torch.equal(theirs[0], t) for t in theirs), "ranks disagree on %s" % name
+        worst_avg = max(worst_avg, rel(got[name], avg))
+        self_dev = max(self_dev, rel(parts[0], parts[1]))
+    parts = [torch.zeros_like(own_flat) for _ in range(world)]
+    dist.all_gather(parts, own_flat)
+    flat_rel = rel(got_flat, sum(parts) / world)
+    if rank == 0:
+        print("DDP_LSTM extras=%d worst_vs_average=%g backbone_vs_average=%g shard0_vs_shard1=%g" % (
+            len(got), worst_avg, flat_rel, self_dev), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     import faulthandler
     faulthandler.dump_traceback_later(100, exit=True)  # a stuck collective names itself instead of hanging the box
     if len(sys.argv) > 1 and sys.argv[1] == "shards":
         main_shards()
+    elif len(sys.argv) > 1 and sys.argv[1] == "lstm":
+        main_lstm()
     else:
         main_identity()

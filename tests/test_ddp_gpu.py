@@ -1,5 +1,6 @@
 """RCCL rehearsal on one GPU: the bucketed all-reduce path of DataParallel3D (side stream, events, AVG)
-under backend "nccl" with a one-rank group, and bench.py launched the way the driver launches N > 1."""
+under backend "nccl" with a one-rank group, and bench.py as a rank of a torch.distributed.run launch (the
+self-launching form, `python bench.py --gpus N`, is covered without a GPU in tests/test_host_cpu.py)."""
 import json
 import os
 import re
@@ -96,6 +97,24 @@ def test_two_ranks_equal_two_micro_shards_with_per_shard_batchnorm():
         assert got["bf16"][0] <= 8e-3 and got["bf16"][1] <= 1e-4
     else:
         assert max(acc_sep, ddp_sep, got["fp32"][0], got["bf16"][0]) <= 0.45
+
+
+def test_recurrent_head_gradients_are_averaged_over_ranks():
+    """MODEL.USE_LSTM under DataParallel3D (reference train.py:43 wraps the WHOLE VedioClfNet, model.py:18-25): the
+    LSTM / act / clf / crit parameters are outside the flat buffer and are averaged at the end of backward.  Two ranks
+    (gloo, sharing the GPU): every rank ends with identical head gradients (exact), equal to the average of the two
+    shards' own gradients to the run-to-run noise of this configuration (2e-3; the shards themselves differ by O(1))."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_HALO_NO_PAD="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_worker.py"), "lstm"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    m = re.search(r"DDP_LSTM extras=(\d+) worst_vs_average=(\S+) backbone_vs_average=(\S+) shard0_vs_shard1=(\S+)", r.stdout)
+    assert m, r.stdout[-2000:]
+    print(m.group(0))
+    assert int(m.group(1)) >= 10
+    assert float(m.group(4)) > 0.3, "the two shards were expected to have different head gradients"
+    assert float(m.group(2)) <= 5e-3 and float(m.group(3)) <= 5e-3
 
 
 def test_bench_under_torchrun_with_rccl_buckets():

@@ -689,6 +689,73 @@ def test_kernels_beyond_two_giga_elements():
     assert torch.equal(yo[tail], yo_t)
 
 
+@pytest.mark.parametrize("kind", ["halo", "pointwise", "strided", "halo_splitk", "stem"])
+def test_sub_batched_conv_keeps_the_shift_of_the_batchnorm_sums(kind):
+    """A conv whose tensor passes the per-launch element limit runs as sub-batches (capi.hip conv_max_batch /
+    stem_max_batch; BASELINE config 4 at batch 64).  The fused finalize of such a call must see sums taken relative to
+    the SAME shift it adds back: with a non-zero shift (every step after the first: the engine passes the previous
+    batch mean) the sub-launches used to accumulate raw sums while the finalize added the shift, doubling the mean.
+    VC_MAX_TENSOR_ELEMS lowers the limit so that a small batch splits three ways; the result must equal the unsplit
+    call's (same output bits; mean / invstd / running statistics / next shift to the order of the float atomics), on
+    two consecutive calls that hand the shift on."""
+    _need_gpu()
+    from vc3d import ops
+    g = torch.Generator().manual_seed(11)
+    N = 5
+    if kind == "stem":
+        T, H, W, Co = 4, 16, 16, 64
+        x = bf16_round(torch.randn(N, 3, T, H, W, generator=g) + 0.7)
+        w = bf16_round(torch.randn(Co, 3, 7, 7, 7, generator=g) * 0.05 + 0.01)
+        xs = ops.stem_pack_input(x.cuda())
+        ws = ops.stem_pack_weight(cl3d_param(w))
+        count = N * T * (H // 2) * (W // 2)
+        per_clip = max(xs.numel() // N, count // N * Co)
+        run = lambda st, fin: ops.stem_fwd(xs, ws, N, T, H, W, Co, stats=st, fin=fin)
+    else:
+        Ci, T, H, W, Co, k, s, p = {"halo": (64, 4, 6, 6, 64, 3, 1, 1), "pointwise": (64, 2, 6, 6, 128, 1, 1, 0),
+                                    "strided": (64, 4, 8, 8, 128, 3, 2, 1), "halo_splitk": (256, 2, 7, 7, 256, 3, 1, 1)}[kind]
+        x = bf16_round(torch.randn(N, Ci, T, H, W, generator=g) + 0.5)
+        w = bf16_round(torch.randn(Co, Ci, k, k, k, generator=g) * (2.0 / (Ci * k ** 3)) ** 0.5 + 0.02)
+        d = ops.conv_desc(N, Ci, T, H, W, Co, k, s, p)
+        xd = to_nthwc_dev(x)
+        wf, _ = ops.pack_weight(cl3d_param(w))
+        To, Ho, Wo = d.out_dims()
+        count = N * To * Ho * Wo
+        per_clip = max(Ci * T * H * W, Co * To * Ho * Wo)
+        run = lambda st, fin: ops.conv3d_fwd(d, xd, wf, stats=st, fin=fin)
+    gamma = (torch.rand(Co, generator=g) + 0.5).cuda()
+    beta = (torch.randn(Co, generator=g) * 0.1).cuda()
+
+    def two_steps():
+        ticket = torch.zeros(64, dtype=torch.int32, device="cuda")
+        rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        shift = torch.zeros(Co, device="cuda")
+        out = []
+        for _ in range(2):
+            st = ops.new_stats(Co, "cuda")
+            fin, prm = ops.bn_fin(ticket, count, gamma, beta, rm, rv, 0.1, 1e-5, shift=shift)
+            y = run(st, fin)
+            torch.cuda.synchronize()
+            out.append((y.clone(), prm.clone(), shift.clone()))
+        return out, rm, rv
+
+    ref, rm0, rv0 = two_steps()
+    assert float(ref[0][2].abs().min()) > 1e-3, "the test needs a non-zero shift in the second call"
+    os.environ["VC_MAX_TENSOR_ELEMS"] = str(2 * per_clip)  # sub-batches of 2, 2 and 1 clips
+    try:
+        got, rm1, rv1 = two_steps()
+    finally:
+        del os.environ["VC_MAX_TENSOR_ELEMS"]
+    for (y0, p0, s0), (y1, p1, s1) in zip(ref, got):
+        assert torch.equal(y0, y1)
+        assert torch.allclose(p0, p1, rtol=2e-5, atol=2e-6), float((p0 - p1).abs().max())
+        assert torch.allclose(s0, s1, rtol=2e-5, atol=2e-6)
+    assert torch.allclose(rm0, rm1, rtol=2e-5, atol=2e-6) and torch.allclose(rv0, rv1, rtol=2e-5, atol=2e-6)
+    # and the mean is the mean: against fp64 on the host
+    yh = got[1][0].double().view(-1, Co)
+    assert torch.allclose(got[1][1][0].double(), yh.mean(0), rtol=0, atol=2e-2 * float(yh.std()))
+
+
 def test_batchnorm_variance_survives_a_large_mean():
     """SURVEY section 7 flagged var = sum x^2 / n - mean^2 in fp32 as cancellation-prone.  The sums are shifted now
     (bn_fin.h): stand-alone statistics relative to row 0 of the tensor, fused conv-epilogue statistics relative to a

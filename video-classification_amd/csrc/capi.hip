@@ -64,11 +64,28 @@ static int conv_check(const vc_conv3d_desc* d, int& To, int& Ho, int& Wo) {
 // interact in a conv, BatchNorm sums accumulate across the launches (atomics into the same buffer), weight gradients
 // accumulate by construction, and the fused finalize (one launch's ticket) becomes the separate finalize launch after
 // the last sub-batch.  Returns the largest sub-batch (== N when no split is needed).
+// element limit of one tensor per launch (32-bit element offsets in the conv kernels).  VC_MAX_TENSOR_ELEMS lowers
+// it: tests use that to drive the sub-batch paths at sizes a reference fits in memory for.
+static long long max_tensor_elems() {
+    const char* e = getenv("VC_MAX_TENSOR_ELEMS");
+    const long long lim = (1ll << 31) - 1;
+    if (e == nullptr) return lim;
+    const long long v = atoll(e);
+    return v > 0 && v < lim ? v : lim;
+}
+// A sub-launch of a sub-batched call takes the SHIFT of the sums (so that every sub-launch accumulates sum (y - s) with
+// the s the final finalize assumes) but neither the fused finalize (ticket) nor a finalize launch of its own (params).
+static VcBnFin shift_only(const VcBnFin* fin) {
+    VcBnFin f;
+    memset(&f, 0, sizeof(f));
+    if (fin != nullptr) f.shift = fin->shift;
+    return f;
+}
 static int conv_max_batch(const vc_conv3d_desc* d, int To, int Ho, int Wo) {
     const long long in_s = (long long)d->Ti * d->Hi * d->Wi * d->Ci;
     const long long out_s = (long long)To * Ho * Wo * d->Co;
     const long long big = in_s > out_s ? in_s : out_s;
-    long long nmax = ((1ll << 31) - 1) / big;
+    long long nmax = max_tensor_elems() / big;
     if (nmax < 1) nmax = 1;
     return nmax < d->N ? (int)nmax : d->N;
 }
@@ -258,10 +275,12 @@ static int conv3d_fwd_impl(const vc_conv3d_desc* d, const void* x, const void* w
     const int nb = conv_max_batch(d, To, Ho, Wo);
     if (nb < d->N) {  // sub-batches (see conv_max_batch)
         const size_t in_s = (size_t)d->Ti * d->Hi * d->Wi * d->Ci, out_s = (size_t)To * Ho * Wo * d->Co;
+        const VcBnFin sub_fin = shift_only(fin);
         for (int n0 = 0; n0 < d->N; n0 += nb) {
             vc_conv3d_desc sub = *d;
             sub.N = d->N - n0 < nb ? d->N - n0 : nb;
-            rc = conv3d_fwd_impl(&sub, (const bf16*)x + n0 * in_s, w, (bf16*)y + n0 * out_s, bn_stats, nullptr, ep_params, ep_relu,
+            rc = conv3d_fwd_impl(&sub, (const bf16*)x + n0 * in_s, w, (bf16*)y + n0 * out_s, bn_stats,
+                                 fin != nullptr && bn_stats != nullptr ? &sub_fin : nullptr, ep_params, ep_relu,
                                  ep_res ? (const bf16*)ep_res + n0 * out_s : nullptr, workspace, ws_bytes, stream);
             if (rc) return rc;
         }
@@ -354,6 +373,7 @@ int vc_conv3d_fwd_bn(const vc_conv3d_desc* d, const void* x, const void* w, void
  * device current) and kept in g_scratch_ptr[]. */
 static __device__ __align__(256) unsigned char vc_static_scratch[VC_STATIC_SCRATCH_BYTES];
 static void* g_scratch_ptr[64];
+static hipError_t g_scratch_err[64];
 static std::once_flag g_scratch_once[64];
 
 static int static_scratch(void** out) {
@@ -362,14 +382,14 @@ static int static_scratch(void** out) {
         vc_set_error("static scratch: no current device (or device index %d >= 64)", dev);
         return -1;
     }
-    hipError_t err = hipSuccess;
     std::call_once(g_scratch_once[dev], [&]() {
         void* ptr = nullptr;
-        err = hipGetSymbolAddress(&ptr, HIP_SYMBOL(vc_static_scratch));
+        const hipError_t err = hipGetSymbolAddress(&ptr, HIP_SYMBOL(vc_static_scratch));
+        g_scratch_err[dev] = err;  // kept: later calls on this device report the lookup's own error
         g_scratch_ptr[dev] = err == hipSuccess ? ptr : nullptr;
     });
     if (g_scratch_ptr[dev] == nullptr) {
-        vc_set_error("static scratch: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(err));
+        vc_set_error("static scratch: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(g_scratch_err[dev]));
         return -1;
     }
     *out = g_scratch_ptr[dev];
@@ -378,7 +398,14 @@ static int static_scratch(void** out) {
 
 extern "C" {
 
-size_t vc_static_scratch_bytes(void) { return VC_STATIC_SCRATCH_BYTES; }
+// Also the warm-up: with a device current, resolves that device's scratch address now, so that the first
+// vc_conv3d_fwd_noalloc may already sit inside a stream capture (where a symbol lookup is not welcome).
+size_t vc_static_scratch_bytes(void) {
+    int dev = -1;
+    void* unused = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) (void)static_scratch(&unused);
+    return VC_STATIC_SCRATCH_BYTES;
+}
 
 int vc_conv3d_fwd_noalloc(const vc_conv3d_desc* d, const void* x, const void* w, void* y, float* bn_stats, void* stream) {
     int To, Ho, Wo;
@@ -437,7 +464,7 @@ static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const 
     // The halo kernel runs several rounds of one workgroup per CU: a ticket round trip at the end of every workgroup
     // costs more there than the separate finalize launch (measured), so the finalize stays a launch of its own.
     int rc = vc_launch_halo(p, plan, S(stream));
-    if (rc || fin == nullptr || stats == nullptr) return rc;
+    if (rc || fin == nullptr || stats == nullptr || fin->params == nullptr) return rc;  // params null: shift_only()
     return vc_ew_bn_finalize(stats, p.Cn, fin->count, fin->gamma, fin->beta, fin->running_mean, fin->running_var,
                              fin->momentum, fin->eps, fin->params, fin->shift, fin->shift_out, S(stream));
 }
@@ -785,7 +812,7 @@ static int stem_max_batch(int N, int T, int H, int W, int Co) {
     const long long in_s = (long long)(T + 6) * (H / 2 + 3) * ((W / 2 + 4) & ~1) * 12;
     const long long out_s = (long long)T * (H / 2) * (W / 2) * Co;
     const long long big = in_s > out_s ? in_s : out_s;
-    long long nmax = ((1ll << 31) - 1) / big;
+    long long nmax = max_tensor_elems() / big;
     if (nmax < 1) nmax = 1;
     return nmax < N ? (int)nmax : N;
 }
@@ -846,8 +873,10 @@ static int stem_fwd_impl(const void* xs, const void* ws, void* y, float* bn_stat
     const int nb = stem_max_batch(N, T, H, W, Co);
     if (nb < N) {  // sub-batches: BatchNorm sums accumulate across the launches, finalize after the last one
         const size_t in_s = vc_stem_packed_input_elems(1, T, H, W), out_s = (size_t)T * (H / 2) * (W / 2) * Co;
+        const VcBnFin sub_fin = shift_only(fin);
         for (int n0 = 0; n0 < N; n0 += nb) {
-            rc = stem_fwd_impl((const bf16*)xs + n0 * in_s, ws, (bf16*)y + n0 * out_s, bn_stats, nullptr, N - n0 < nb ? N - n0 : nb, T,
+            rc = stem_fwd_impl((const bf16*)xs + n0 * in_s, ws, (bf16*)y + n0 * out_s, bn_stats,
+                               fin != nullptr && bn_stats != nullptr ? &sub_fin : nullptr, N - n0 < nb ? N - n0 : nb, T,
                                H, W, Co, stream);
             if (rc) return rc;
         }

@@ -1,7 +1,7 @@
 """Global configuration: same keys and defaults as the reference's edict
 (/root/reference/lib/core/config.py:12-69) on a dependency-free attribute dict
 (easydict is not required).  Added keys: MODEL.CLIP_LEN, MODEL.CROP_SIZE, MODEL.DTYPE,
-TRAIN.BUCKET_MB (gradient all-reduce bucket size), TEST.NUM_CLIPS / NUM_CROPS.
+TRAIN.BUCKET_MB (gradient all-reduce bucket size), TRAIN.GRAD_DTYPE, TEST.NUM_CLIPS / NUM_CROPS.
 """
 
 
@@ -72,6 +72,7 @@ config.TRAIN.BATCH_SIZE = 32
 config.TRAIN.SHUFFLE = True
 config.TRAIN.PRINT_EVERY = 100
 config.TRAIN.BUCKET_MB = 32
+config.TRAIN.GRAD_DTYPE = ''  # wire format of the gradient all-reduce: '' / 'fp32' (default, as DataParallel sums) or 'bf16'
 config.TRAIN.RESUME = ''  # checkpoint.pth written by train.py every epoch: model + optimizer + scheduler + epoch
 
 # testing

@@ -123,7 +123,7 @@ def main(argv=None):
     world, rank, dev = setup_distributed(cfg)
     logger = create_logger(cfg, 'train')
     model = create_model(cfg, is_train=True).to(dev)
-    net = DataParallel3D(model, bucket_mb=cfg.TRAIN.BUCKET_MB) if world > 1 else model
+    net = DataParallel3D(model, bucket_mb=cfg.TRAIN.BUCKET_MB, grad_dtype=cfg.TRAIN.get('GRAD_DTYPE') or None) if world > 1 else model
     criterion = Loss(cfg).to(dev)
     optimizer = create_optimizer(cfg, model)
     if optimizer is None:

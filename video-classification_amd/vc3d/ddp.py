@@ -174,9 +174,13 @@ class DataParallel3D(torch.nn.Module):
         self.group = group
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.tail_bytes = int(tail_mb * (1 << 20))
-        # gradients travel as bf16 by default (half the xGMI bytes; fp32 master gradients); VC_DDP_GRAD_DTYPE=fp32 opts out
-        self.grad_dtype = grad_dtype or os.environ.get("VC_DDP_GRAD_DTYPE", "bf16")
+        # Gradients travel as fp32 by default: the reference's DataParallel sums fp32 gradients (reduce_add_coalesced),
+        # and a bf16 wire format rounds each rank's gradient AND every ring step of RCCL's bf16 reduction.  bf16 on the
+        # wire (half the xGMI bytes; master gradients stay fp32) is opt-in: grad_dtype="bf16", config TRAIN.GRAD_DTYPE
+        # through train.py, or VC_DDP_GRAD_DTYPE=bf16.
+        self.grad_dtype = grad_dtype or os.environ.get("VC_DDP_GRAD_DTYPE", "fp32")
         self.reducer = None
+        self._extras_queued = False
         self._sync = True
         broadcast_module(model, 0, group)
         eng = model.backbone.engine
@@ -203,6 +207,41 @@ class DataParallel3D(torch.nn.Module):
         r = self._ensure()
         r.enabled = self._sync
         r.finish()
+        # Parameters that live outside the engine's flat buffer -- the recurrent head of MODEL.USE_LSTM (LSTMCell,
+        # act_head, clf_haed, crit_head: reference model.py:18-25, wrapped by DataParallel as part of the whole model at
+        # train.py:43) -- are averaged once the WHOLE backward pass has finished (autograd's end-of-backward callback,
+        # as torch DDP does): replicas would otherwise drift apart silently.
+        if self._sync and not self._extras_queued and self.extra_params():
+            self._extras_queued = True
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._reduce_extras)
+            except RuntimeError:  # engine.backward called outside autograd: every gradient is final already
+                self._reduce_extras()
+
+    def extra_params(self):
+        eng = self.module.backbone.engine
+        flat = {id(p) for p, _, _ in eng.grad_ranges}
+        return [p for p in self.module.parameters() if p.requires_grad and id(p) not in flat]
+
+    def _reduce_extras(self):
+        self._extras_queued = False
+        if not dist.is_initialized():
+            return
+        world = dist.get_world_size(self.group)
+        if world == 1 and not FORCE_COMM:
+            return
+        grads = [p.grad for p in self.extra_params() if p.grad is not None]
+        if not grads:
+            return
+        flat = torch._utils._flatten_dense_tensors(grads)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:  # gloo (tests; ranks may share one GPU): staged through the host
+            host = flat.cpu()
+            dist.all_reduce(host, group=self.group)
+            flat.copy_(host.div_(world))
+        for g, v in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(v)
 
     @contextlib.contextmanager
     def no_sync(self):
