@@ -455,3 +455,53 @@ def test_resume_restores_optimizer_scheduler_and_epoch(tmp_path, monkeypatch):
     assert rel_l2(w(first), w(full)) > 1e-2, "the second epoch was expected to move the weights"
     for h in list(logging.getLogger().handlers):
         logging.getLogger().removeHandler(h)
+
+
+@pytest.mark.parametrize("depth,classes", [(18, 101), (50, 400)])
+def test_config5_thirty_views_per_video_through_validate(depth, classes):
+    """BASELINE config 5 as specified: every video = 10 clips x 3 crops = 30 views of 3 x 16 x 112 x 112, through valid.py's
+    loader (MultiViewClips + DataLoader) and validate() (reference valid.py:28-61, function.py:117-149): eval-mode
+    BatchNorm, TEST.BATCH_SIZE clips per forward, the 30 views' logits averaged per video before the arg-max.
+    Oracle: the stock-torch fp32 model on the same 60 clips (CPU).  Bars: the videos' averaged logits rel-L2 <= 3e-2
+    (the whole-net logits bar), validate()'s mean cross-entropy within 2 % of the oracle's on its own averaged logits,
+    top-1 against the oracle's arg-max = 1.0 when the oracle's margin exceeds the logit error."""
+    import torch.utils.data
+    from core.function import validate
+    from core.loss import Loss
+    from dataset.dataset import MultiViewClips
+    from helpers import build_pair, rel_l2
+    oracle, prod, cfg = build_pair(depth, classes)
+    cfg.TEST.BATCH_SIZE, cfg.TEST.NUM_CLIPS, cfg.TEST.NUM_CROPS, cfg.TEST.PRINT_EVERY = 32, 10, 3, 100
+    views = cfg.TEST.NUM_CLIPS * cfg.TEST.NUM_CROPS
+    ds = MultiViewClips(2, views, 16, 112, classes)
+    assert ds[0][0].shape == (30, 3, 16, 112, 112)
+    vids = torch.stack([ds[i][0] for i in range(2)])
+    oracle.eval()
+    with torch.no_grad():
+        ref = torch.stack([torch.cat([oracle(vids[i, s:s + 10]) for s in range(0, 30, 10)]).mean(0) for i in range(2)])
+    pred = ref.argmax(1)
+
+    class Labelled(torch.utils.data.Dataset):  # the same videos, labelled with the oracle's prediction
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            return ds[i][0], int(pred[i])
+
+    loader = torch.utils.data.DataLoader(Labelled(), batch_size=max(1, cfg.TEST.BATCH_SIZE // views), shuffle=False)
+    prod.eval()
+    acc = validate(cfg, loader, prod, Loss(cfg), 0)
+    last = validate.last
+    with torch.no_grad():
+        got = torch.stack([torch.cat([prod(vids[i, s:s + 15].cuda())[1] for s in range(0, 30, 15)]).mean(0) for i in range(2)])
+    err = rel_l2(got, ref)
+    ref_loss = float(torch.nn.functional.cross_entropy(ref, pred))
+    top2 = ref.topk(2, dim=1).values
+    margin = float((top2[:, 0] - top2[:, 1]).min())
+    print("config 5, R3D-%d: averaged logits rel-L2 %.3e, loss %.4f (oracle %.4f), top-1 %.2f, oracle margin %.3e"
+          % (depth, err, last["loss"], ref_loss, acc, margin))
+    assert last["count"] == 2
+    assert err <= 3e-2
+    assert abs(last["loss"] - ref_loss) <= 0.02 * ref_loss + 1e-3
+    if margin > 4 * float((got.cpu() - ref).abs().max()):
+        assert acc == 1.0 and last["top5"] == 1.0
