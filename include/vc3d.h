@@ -16,8 +16,10 @@
  *  - conv weights (bf16) are [Cout][kt][kh][kw][Cin] for forward / wgrad and
  *    [Cin][kt][kh][kw][Cout] for dgrad; vc_pack_weight makes both from the fp32 master
  *    (which is torch's channels_last_3d storage of a [Cout][Cin][kt][kh][kw] parameter).
- *  - "stats"/"sums" buffers are float [VC_STAT_REPLICAS][2][C], zeroed by the caller
- *    before the kernel that accumulates into them.
+ *  - "stats"/"sums" buffers are 256 * C bytes (float [VC_STAT_REPLICAS][2][C]), 256-byte aligned, zeroed by the
+ *    caller before the kernel that accumulates into them; their content is the library's (float replicas by
+ *    default, 64-bit integer limbs in deterministic mode: vc_set_deterministic) and is read back only by the
+ *    library's finalize steps.
  *  - "bn params" are float [4][C]: mean, invstd, scale = gamma*invstd, shift = beta-mean*scale.
  */
 #ifndef VC3D_H
@@ -47,6 +49,16 @@ typedef struct vc_pool3d_desc {
 
 const char* vc_last_error(void);
 int vc_abi_version(void);
+
+/* Deterministic-reduction mode (the reference has no counterpart -- cuDNN's BatchNorm sums are
+ * order-dependent too).  Process-wide; default off, or on when VC_DETERMINISTIC=1 is in the environment at the first
+ * launch.  On: every BatchNorm sum (forward statistics in the conv epilogues, split-K finalize, stand-alone and folded
+ * backward reductions) is accumulated as exact 64-bit fixed-point integers instead of float atomics, so results do not
+ * depend on the order in which workgroups finish: two runs of the same step are bit-identical.  Set it before the first
+ * step and do not flip it between a kernel that accumulates into a buffer and the finalize that reads it.  Exact for
+ * partial sums of magnitude [2^-21, 2^36); a non-finite or larger partial sum makes the total NaN. */
+int vc_set_deterministic(int32_t on);
+int vc_get_deterministic(void);
 
 /* ---- Conv3d (bf16 MFMA implicit GEMM).  Replaces nn.Conv2d at
  * reference lib/models/backbone.py:19-20 (conv3x3), :70-76 (Bottleneck 1x1/3x3/1x1),

@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def det_mode():
+    """deterministic BatchNorm sums for the test (vc_set_deterministic): results repeat bit for bit, so bars need no
+    allowance for the arrival order of float atomics."""
+    from vc3d import ops
+    prev = ops.set_deterministic(True)
+    yield
+    ops.set_deterministic(prev)

@@ -23,10 +23,10 @@ def _free_port():
 
 
 def _torchrun(script_args, timeout=300):
-    # VC_HALO_NO_PAD=1: with the unpadded halo form every kernel of this small configuration accumulates its
-    # BatchNorm sums in a fixed order, so two plain runs agree to ~1e-5 and the comparison below is sharp (the
-    # tiny 8-clip network amplifies last-bit differences of fp32 atomics to percents otherwise)
-    env = dict(os.environ, VC_DDP_FORCE_COMM="1", HSA_ENABLE_IPC_MODE_LEGACY="0", VC_HALO_NO_PAD="1")
+    # VC_DETERMINISTIC=1 (round 3): the BatchNorm sums are exact integer accumulations, so two plain runs are
+    # bit-identical whatever runs beside them and the comparisons below are exact (rounds 1-2 needed the unpadded halo
+    # form and bars tied to the measured rerun noise: the tiny network amplifies last-bit differences to percents)
+    env = dict(os.environ, VC_DDP_FORCE_COMM="1", HSA_ENABLE_IPC_MODE_LEGACY="0", VC_DETERMINISTIC="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -38,14 +38,10 @@ def test_bucketed_allreduce_single_rank_rccl_identity_and_injected_doubling():
     each bucket, the final gradients are 2x the plain ones: a bucket launched before its last gradient was final
     (wrong event order between the backward stream, the weight-gradient stream and the bucket stream) would miss that
     gradient's doubling and be off by O(1) in that parameter, which the identity cannot show.
-    Noise model, from the per-parameter table the worker prints (DDP_PARAMS): two plain runs schedule their
-    workgroups alike and differ by ~1e-6; kernels running beside backward (RCCL's, or the injected ones) change the
-    arrival order of the atomics, a last-bit change of a BatchNorm mean flips a few ReLU masks, and the deviation
-    then shows in EVERY parameter upstream of that layer at a similar relative size (median ~ worst), up to a few
-    1e-4 on this 8-clip network -- the same mechanism that gives 5e-2 between the fused and the separate finalize in
-    tests/test_net_gpu.py.  An ordering bug is different in kind: one parameter (one bucket) off by 0.1-1 while the
-    median stays at the noise.  Bars: whole-buffer rel-L2 <= 2e-3 for both runs, and no single parameter further
-    than 2e-2 from its expected value (identity or doubled)."""
+    Run in deterministic mode (VC_DETERMINISTIC=1), where a plain step repeats itself bit for bit: the wrapped step's
+    gradients and parameters must EQUAL the plain step's (an AVG over one rank is exact), and the injected run must
+    be exactly 2x in every parameter (a power of two: no rounding).  Bars: 0 for the rerun, <= 1e-7 for the others
+    (rounds 1-2, without the mode, had to allow 2e-3 / 2e-2 for the arrival order of the BatchNorm float atomics)."""
     r = _torchrun([os.path.join(ROOT, "tests", "ddp_worker.py")])
     assert r.returncode == 0, r.stderr[-2000:]
     print("\n".join(ln for ln in r.stdout.splitlines() if ln.startswith("DDP_")))
@@ -53,12 +49,12 @@ def test_bucketed_allreduce_single_rank_rccl_identity_and_injected_doubling():
                   r"loss=\S+ buckets=(\d+) finite=(\d)", r.stdout)
     assert m, r.stdout[-2000:]
     grad_rel, param_rel, rerun_grad, rerun_param, inject_rel = (float(m.group(i)) for i in range(1, 6))
-    assert rerun_grad < 1e-3, "the plain step is expected to be repeatable in this configuration"
-    assert grad_rel <= max(4 * rerun_grad, 2e-3) and param_rel <= max(4 * rerun_param, 2e-5)
-    assert inject_rel <= max(4 * rerun_grad, 2e-3)
+    assert rerun_grad == 0.0 and rerun_param == 0.0, "deterministic mode: the plain step must repeat bit for bit"
+    assert grad_rel <= 1e-7 and param_rel <= 1e-7
+    assert inject_rel <= 1e-7
     for tag in ("wrapped", "injected_x2"):
         worst = re.search(r"DDP_PARAMS %s worst \['[^=]+=([^']+)'" % tag, r.stdout)
-        assert worst and float(worst.group(1)) <= 2e-2, (tag, worst and worst.group(0))
+        assert worst and float(worst.group(1)) <= 1e-6, (tag, worst and worst.group(0))
     assert int(m.group(6)) > 2 and m.group(7) == "1"
 
 
@@ -68,16 +64,11 @@ def test_two_ranks_equal_two_micro_shards_with_per_shard_batchnorm():
     host: two RCCL ranks cannot share the box's one GPU), against ONE process that runs the two halves as sequential
     micro-shards with per-shard BatchNorm and averages the accumulated gradients, and against the average of two
     separate single-shard runs.
-    Noise model (scripts/repro_trace.py): the BatchNorm sums are fp32 atomics; when their arrival order differs
-    between two runs, a last-bit change of one mean re-rounds a few bf16 activations and within three layers the two
-    runs carry independent bf16 rounding noise: logits then differ by 1e-2 and gradients by 0.2 -- the bf16 noise
-    floor, the same figures as tests/test_oracle_cpu.py::test_end_to_end_gradient_floor_of_bf16_operands -- and no
-    further.  When the order repeats (it does for 8 clips per rank in this configuration) the runs are bit-identical
-    outside the stem.  The worker measures which case it is in (DDP_CHECK rerun):
-      rerun < 1e-3: the ranks' averaged gradients equal the micro-shard forms to max(4 x rerun, 2e-3) with fp32 buckets,
-                    8e-3 with bf16 buckets (2^-9 rounding of each rank's gradient and of the average);
-      otherwise:    only the floor can be asserted (<= 0.45: a missing or doubled average would read 0.5-1.0)."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_HALO_NO_PAD="1")
+    Run in deterministic mode (VC_DETERMINISTIC=1): a shard's step repeats itself bit for bit (DDP_CHECK rerun = 0), so
+    the bars are those of the arithmetic alone: fp32 buckets -- the ranks' averaged gradients equal the micro-shard forms
+    to 1e-6 (the same two fp32 gradients, added in a different place); bf16 buckets (opt-in) -- 8e-3 (2^-9 rounding of
+    each rank's gradient and of the average).  Rounds 1-2 had to tie these bars to a measured rerun noise."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_DETERMINISTIC="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_worker.py"), "shards"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
@@ -91,20 +82,17 @@ def test_two_ranks_equal_two_micro_shards_with_per_shard_batchnorm():
     rerun, acc_sep, ddp_sep, s01 = (float(chk.group(i)) for i in range(1, 5))
     assert s01 > 0.5, "the two shards were expected to have different gradients"
     assert got["fp32"][2] > 2
-    if rerun < 1e-3:
-        bar = max(4 * rerun, 2e-3)
-        assert acc_sep <= bar and ddp_sep <= bar and got["fp32"][0] <= bar and got["fp32"][1] <= 2e-5
-        assert got["bf16"][0] <= 8e-3 and got["bf16"][1] <= 1e-4
-    else:
-        assert max(acc_sep, ddp_sep, got["fp32"][0], got["bf16"][0]) <= 0.45
+    assert rerun == 0.0, "deterministic mode: a shard's step must repeat bit for bit"
+    assert acc_sep <= 1e-6 and ddp_sep <= 1e-6 and got["fp32"][0] <= 1e-6 and got["fp32"][1] <= 1e-6
+    assert got["bf16"][0] <= 8e-3 and got["bf16"][1] <= 1e-4
 
 
 def test_recurrent_head_gradients_are_averaged_over_ranks():
     """MODEL.USE_LSTM under DataParallel3D (reference train.py:43 wraps the WHOLE VedioClfNet, model.py:18-25): the
     LSTM / act / clf / crit parameters are outside the flat buffer and are averaged at the end of backward.  Two ranks
     (gloo, sharing the GPU): every rank ends with identical head gradients (exact), equal to the average of the two
-    shards' own gradients to the run-to-run noise of this configuration (2e-3; the shards themselves differ by O(1))."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_HALO_NO_PAD="1")
+    shards' own gradients to fp32 rounding (deterministic mode: 1e-5; the shards themselves differ by O(1))."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_DETERMINISTIC="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_worker.py"), "lstm"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
@@ -114,7 +102,7 @@ def test_recurrent_head_gradients_are_averaged_over_ranks():
     print(m.group(0))
     assert int(m.group(1)) >= 10
     assert float(m.group(4)) > 0.3, "the two shards were expected to have different head gradients"
-    assert float(m.group(2)) <= 5e-3 and float(m.group(3)) <= 5e-3
+    assert float(m.group(2)) <= 1e-5 and float(m.group(3)) <= 1e-5
 
 
 def test_bench_under_torchrun_with_rccl_buckets():

@@ -335,53 +335,48 @@ def test_weight_edits_through_param_data_need_invalidate_weights():
             assert rel_l2(evaluate(model), evaluate(fresh2)) <= 1e-3
 
 
-def test_training_trajectory_tracks_the_fp32_oracle():
+def test_training_trajectory_tracks_the_fp32_oracle(det_mode):
     """Is bf16 storage + bf16 MFMA "good enough" for training?  Same initial weights, same fixed batch, same SGD
     (momentum 0.9): the product path on the GPU and the fp32 torch oracle on the CPU are trained side by side for 16
     steps.  Single gradients cannot be compared tightly at random initialisation (tests/test_net_gpu.py,
     tests/test_oracle_cpu.py::test_end_to_end_gradient_floor_of_bf16_operands); what training needs is that the loss
     follows the fp32 trajectory: every one of the first 8 losses within 5 % + 0.05 of the oracle's, and the batch is
     fitted as well as the oracle fits it (final loss <= 1.5 x the oracle's + 0.1).
-    The product is not bit-reproducible from run to run (the BatchNorm sums are float atomics, and a last-bit difference
-    there flips bf16 roundings downstream): on this 8-clip batch, which the optimizer fits in three steps, identical runs
-    gave 0.192, 0.233, 0.248 and 0.260 at step 3 against the oracle's 0.192.  So TWO product replicas are trained from
-    the same initial weights and the bar on their mean is widened by their own spread at that step -- the tolerance
-    follows the measured run-to-run noise instead of a constant that one run in four exceeded."""
+    Run in deterministic mode (round 3): ONE replica, a fixed bar, the same numbers in every run.  Rounds 1-2 trained
+    two replicas and widened the bar by their spread, because identical runs gave 0.192 ... 0.260 at step 3 (oracle
+    0.192): float-atomic BatchNorm sums, a last-bit difference, and an 8-clip batch fitted in three steps.  Measured in
+    deterministic mode: 2.327 / 0.878 / 0.183 / 0.034 against the oracle's 2.328 / 0.852 / 0.192 / 0.031."""
     from helpers import build_pair
     from oracle.r3d_torch import synthetic_batch
     from utils.utils import create_optimizer
     oracle, prod, cfg = build_pair(18, 8)
-    _, prod2, _ = build_pair(18, 8)
     cfg.TRAIN.OPTIMIZER, cfg.TRAIN.LR, cfg.TRAIN.MOMENTUM, cfg.TRAIN.WD, cfg.TRAIN.NESTEROV = "sgd", 0.02, 0.9, 1e-4, False
-    opts = [create_optimizer(cfg, m) for m in (prod, prod2)]
+    opt = create_optimizer(cfg, prod)
     topt = torch.optim.SGD(oracle.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
     x, y = synthetic_batch(8, 8, 64, 64, 8, 77)
     xc, yc = x.cuda(), y.cuda()
     oracle.train()
     prod.train()
-    prod2.train()
-    lps, lr_ = ([], []), []
+    lp, lr_ = [], []
     for _ in range(16):
-        for m, opt, lp in zip((prod, prod2), opts, lps):
-            _, score, _ = m(xc)
-            loss = F.cross_entropy(score, yc)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-            lp.append(float(loss))
+        _, score, _ = prod(xc)
+        loss = F.cross_entropy(score, yc)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        lp.append(float(loss.detach()))
         lo = F.cross_entropy(oracle(x), y)
         topt.zero_grad()
         lo.backward()
         topt.step()
-        lr_.append(float(lo))
-    print("product", ["%.3f" % v for v in lps[0]])
-    print("replica", ["%.3f" % v for v in lps[1]])
+        lr_.append(float(lo.detach()))
+    print("product", ["%.3f" % v for v in lp])
     print("oracle ", ["%.3f" % v for v in lr_])
-    assert abs(lps[0][0] - lps[1][0]) <= 1e-2 * lr_[0], "the two replicas start from the same weights"
-    for a1, a2, b in list(zip(lps[0], lps[1], lr_))[:8]:
-        assert abs(0.5 * (a1 + a2) - b) <= 0.05 * b + 0.05 + abs(a1 - a2)
+    assert abs(lp[0] - lr_[0]) <= 5e-3 * lr_[0], "same weights, same batch: the first loss is the forward parity"
+    for a, b in list(zip(lp, lr_))[:8]:
+        assert abs(a - b) <= 0.05 * b + 0.05
     assert lr_[-1] < 0.5 * lr_[0], "the oracle itself was expected to fit the batch"
-    assert max(lps[0][-1], lps[1][-1]) <= 1.5 * lr_[-1] + 0.1
+    assert lp[-1] <= 1.5 * lr_[-1] + 0.1
 
 
 def test_validate_top5_and_test_step_clips():

@@ -35,17 +35,9 @@ struct VcBnBwdFin {  // backward: sums (sum g, sum g*xhat) -> coef [2][C]; dgamm
 };
 
 template <bool AGENT>
-__device__ __forceinline__ float vc_stat_load(const float* p) {
-    return AGENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-template <bool AGENT>
 __device__ __forceinline__ void vc_stat_sum(const float* stats, int C, int c, float& s, float& q) {
-    s = 0.f, q = 0.f;
-#pragma unroll  // all 2 x VC_STAT_REPLICAS loads in flight at once, summed in replica order
-    for (int r = 0; r < VC_STAT_REPLICAS; ++r) {
-        s += vc_stat_load<AGENT>(stats + (size_t)r * 2 * C + c);
-        q += vc_stat_load<AGENT>(stats + (size_t)r * 2 * C + C + c);
-    }
+    s = vc_stat_total<AGENT>(stats, C, c);      // common.h: float replicas in replica order, or the deterministic limbs
+    q = vc_stat_total<AGENT>(stats, C, C + c);
 }
 
 template <bool AGENT>

@@ -1,6 +1,7 @@
 // extern "C" entry points of libvc3d.so (declared in include/vc3d.h): validate shapes on the
 // host, build the gather descriptions and launch.  Nothing here allocates or synchronises.
 #include <stdarg.h>
+#include <atomic>
 #include <cmath>
 #include <mutex>
 #include <stdio.h>
@@ -20,6 +21,23 @@ void vc_set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- deterministic BatchNorm sums (common.h: vc_stat_add): a process-wide mode
+static std::atomic<int> g_det_mode{-1};  // -1: not decided yet (VC_DETERMINISTIC read at first use)
+bool vc_det_mode() {
+    int m = g_det_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("VC_DETERMINISTIC");
+        m = (e != nullptr && e[0] != '\0' && e[0] != '0') ? 1 : 0;
+        g_det_mode.store(m, std::memory_order_relaxed);
+    }
+    return m == 1;
+}
+extern "C" int vc_set_deterministic(int32_t on) {
+    g_det_mode.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int vc_get_deterministic(void) { return vc_det_mode() ? 1 : 0; }
 
 #define VC_REQUIRE(cond, ...)         \
     do {                              \

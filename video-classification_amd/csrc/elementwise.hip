@@ -199,8 +199,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restri
         float s = 0.f;
 #pragma unroll 8
         for (int rr = 0; rr < 32; ++rr) s += sm[(rr * 8 + gg) * 17 + k];
-        float* dst = sums + (size_t)(rs & (VC_STAT_REPLICAS - 1)) * 2 * C;
-        atomicAdd(dst + (k < 8 ? 0 : C) + (cs * 8 + gg) * 8 + (k & 7), s);
+        vc_stat_add(sums, (unsigned)rs, C, (k < 8 ? 0 : C) + (cs * 8 + gg) * 8 + (k & 7), s);
     }
     if (MODE == 0) vc_bn_fin_last(ffin, sums, C);
     else vc_bn_bwd_fin_last(bfin, sums, C);
@@ -286,8 +285,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
             float s = 0.f;
 #pragma unroll 8
             for (int rr = 0; rr < 32; ++rr) s += sm[(rr * 8 + gg) * 17 + k];
-            float* dst = stats + (size_t)(rs & (VC_STAT_REPLICAS - 1)) * 2 * C;
-            atomicAdd(dst + (k < 8 ? 0 : C) + (cs * 8 + gg) * 8 + (k & 7), s);
+            vc_stat_add(stats, (unsigned)rs, C, (k < 8 ? 0 : C) + (cs * 8 + gg) * 8 + (k & 7), s);
         }
         vc_bn_fin_last(fin, stats, C);
     }
@@ -878,11 +876,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pooled_kernel(const bf16* _
     __syncthreads();
     if (threadIdx.x < groups && !idle) {
         const int rl = 256 / groups;
-        float* dst = sums + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * C;
         for (int k = 0; k < 16; ++k) {
             float s = 0.f;
             for (int rr = 0; rr < rl; ++rr) s += sm[(rr * groups + threadIdx.x) * 17 + k];
-            atomicAdd(dst + (k < 8 ? 0 : C) + threadIdx.x * 8 + (k & 7), s);
+            vc_stat_add(sums, blockIdx.x, C, (k < 8 ? 0 : C) + threadIdx.x * 8 + (k & 7), s);
         }
     }
     vc_bn_bwd_fin_last(fin, sums, C);
@@ -1454,6 +1451,7 @@ static inline int vc_check_launch() {
 int vc_ew_bn_finalize(const float* stats, int C, float count, const float* gamma, const float* beta, float* rmean,
                       float* rvar, float momentum, float eps, float* params, const float* shift, float* shift_out,
                       hipStream_t s) {
+    stats = vc_det_tag(stats);
     VC_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, C, count, gamma, beta, rmean,
                        rvar, momentum, eps, params, shift, shift_out);
     return VC_CHECK_LAUNCH();
@@ -1500,6 +1498,7 @@ static void chan_reduce_geometry(long rows, int C, int& grid, int& CS) {
 int vc_ew_bn_stats(const void* y, float* sums, long rows, int C, float* shift_out, hipStream_t s) {
     int grid, slices;
     chan_reduce_geometry(rows, C, grid, slices);
+    sums = vc_det_tag(sums);
     VC_LAUNCH((chan_reduce_kernel<0, 0>), dim3(grid), dim3(256), 0, s, (const bf16x8*)y, (const bf16x8*)nullptr,
                        (const bf16x8*)nullptr, (const float*)nullptr, sums, rows, C, slices, VcBnFin{}, VcBnBwdFin{},
                        shift_out);
@@ -1511,6 +1510,7 @@ int vc_ew_bn_bwd_reduce(const void* y, const void* dz, const void* aux, const fl
     chan_reduce_geometry(rows, C, grid, slices);
     const bf16x8 *yy = (const bf16x8*)y, *dd = (const bf16x8*)dz, *aa = (const bf16x8*)aux;
     const VcBnBwdFin bf = fin ? *fin : VcBnBwdFin{};
+    sums = vc_det_tag(sums);
     if (mask == 0)
         VC_LAUNCH((chan_reduce_kernel<1, 0>), dim3(grid), dim3(256), 0, s, yy, dd, aa, params, sums, rows, C, slices,
                   VcBnFin{}, bf, (float*)nullptr);
@@ -1532,6 +1532,7 @@ int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void
                           long rows, int C, const VcBnFin* fin, hipStream_t s) {
     int grid, slices;
     chan_reduce_geometry(rows, C, grid, slices);
+    stats = vc_det_tag(stats);
     if (stats)
         VC_LAUNCH((splitk_finalize_kernel<true>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
                   accumulate, stats, rows, C, slices, fin ? *fin : VcBnFin{}, fin ? fin->shift : (const float*)nullptr);
@@ -1554,6 +1555,7 @@ int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, 
 }
 int vc_ew_bn_bwd_finalize(const float* sums, int C, float count, float* coef, float* dgamma, float* dbeta,
                           hipStream_t s) {
+    sums = vc_det_tag(sums);
     VC_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, count, coef, dgamma,
                        dbeta);
     return VC_CHECK_LAUNCH();
@@ -1733,6 +1735,7 @@ int vc_ew_bn_bwd_reduce_pooled(const void* y, const void* dout, const uint8_t* i
                                const VcPoolGeom& g, const VcBnBwdFin* fin, hipStream_t s) {
     const long total = (long)g.N * g.To * g.Ho * g.Wo * (g.C / 8);
     const int groups = g.C / 8;
+    sums = vc_det_tag(sums);
     if (pooled != nullptr && groups <= 256 && 256 % groups == 0 && g.C % 64 == 0 && getenv("VC_POOLRED_GATHER") == nullptr) {
         // the sums are a plain streaming reduction over the two pooled tensors (chan_reduce_kernel: 5-6 TB/s); the one-
         // kernel form below spent 117 us on 0.1 GB, most of it in its 262 k float atomics.  A small second launch takes

@@ -630,8 +630,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) s += sstat[w * 128 + tid];
-        float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
-        atomicAdd(srep + (tid < 64 ? 0 : p.Cn) + co0 + (tid & 63), s);
+        vc_stat_add(p.stats, blockIdx.x, p.Cn, (tid < 64 ? 0 : p.Cn) + co0 + (tid & 63), s);
     }
     {
         // each wave streams its own WS x 64 tile: 8 rows of 128 bytes per instruction
@@ -794,6 +793,7 @@ extern "C" void vc_debug_halo_stamps(long long* buf) { g_halo_dbg = buf; }  // t
 
 int vc_launch_halo(VcHaloParams& p, const VcHaloPlan& plan, hipStream_t stream) {
     p.dbg = g_halo_dbg;
+    p.stats = vc_det_tag(p.stats);
     if (p.Cs % 64 != 0 || p.Cn % 64 != 0 || p.ntaps < 1 || p.ntaps > 32 || (p.ntaps & 1) == 0) {
         vc_set_error("halo conv: bad channels/taps (Cs=%d Cn=%d taps=%d)", p.Cs, p.Cn, p.ntaps);
         return -2;

@@ -410,13 +410,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const VcIgemmParams p) {
             }
         }
         __syncthreads();
-        float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
         for (int i = tid; i < 2 * BCO; i += 256) {
             const int mom = i / BCO, c = i - mom * BCO;
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < Cfg::WM; ++w) v += sred[(w * 2 + mom) * BCO + c];
-            atomicAdd(srep + mom * p.Cn + co0 + c, v);
+            vc_stat_add(p.stats, blockIdx.x, p.Cn, mom * p.Cn + co0 + c, v);
         }
     }
     if (p.partial == nullptr) vc_bn_fin_last<4>(p.fin, p.stats, p.Cn);
@@ -476,15 +475,20 @@ int vc_launch_igemm(const VcIgemmParams& p, int mode, hipStream_t stream) {
         vc_set_error("igemm: ntaps=%d out of range", p.ntaps);
         return -2;
     }
-    if (mode == 1) return launch_igemm<64, 256, 1>(p, stream);
+    if (mode == 1) {
+        VcIgemmParams s1 = p;
+        s1.stats = vc_det_tag(s1.stats);
+        return launch_igemm<64, 256, 1>(s1, stream);
+    }
     VcIgemmParams q = p;
+    q.stats = vc_det_tag(q.stats);
     q.pointwise = p.ncls <= 1 && p.ntaps == 1 && p.taps[0].ot == 0 && p.taps[0].oh == 0 && p.taps[0].ow == 0 &&
                   p.taps[0].src_off == 0 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.Ts == p.Ta && p.Hs == p.Ha &&
                   p.Ws == p.Wa && p.out_w == p.Cn && p.out_h == p.Wa * p.Cn && p.out_t == p.Ha * p.Wa * p.Cn &&
                   p.out_n == p.Ta * p.Ha * p.Wa * p.Cn && getenv("VC_NO_POINTWISE") == nullptr;
     if (q.pointwise && p.splits <= 1 && p.partial == nullptr && getenv("VC_NO_PW_KERNEL") == nullptr) {
         VcPwParams w = {};  // the dense GEMM kernel (pw_conv.hip)
-        w.src = p.src, w.wgt = p.wgt, w.out = p.out + p.out_base, w.stats = p.stats, w.stat_shift = p.stat_shift;
+        w.src = p.src, w.wgt = p.wgt, w.out = p.out + p.out_base, w.stats = q.stats, w.stat_shift = p.stat_shift;
         w.fin = p.fin, w.ep_params = p.ep_params, w.ep_relu = p.ep_relu;
         w.ep_res = p.ep_res != nullptr ? p.ep_res + p.out_base : nullptr;
         w.M = p.M, w.K = p.Cs, w.Cn = p.Cn, w.accumulate = p.accumulate;

@@ -289,8 +289,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
             float v = 0.f;
 #pragma unroll 8
             for (int rr = 0; rr < RSTEP; ++rr) v += sm[(rr * PPR + gg) * 17 + k];
-            float* srep = sums + (size_t)(bx & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
-            atomicAdd(srep + (k < 8 ? 0 : p.Cn) + co0 + gg * 8 + (k & 7), v);
+            vc_stat_add(sums, (unsigned)bx, p.Cn, (k < 8 ? 0 : p.Cn) + co0 + gg * 8 + (k & 7), v);
         }
     } else if (sums != nullptr) {
         float* sred = (float*)smem;  // [WM][2][BCO]
@@ -311,13 +310,12 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
             }
         }
         __syncthreads();
-        float* srep = sums + (size_t)(bx & (VC_STAT_REPLICAS - 1)) * 2 * p.Cn;
         for (int i = tid_e; i < 2 * BCO; i += 256) {
             const int mom = i / BCO, c = i - mom * BCO;
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < Cfg::WM; ++w) v += sred[(w * 2 + mom) * BCO + c];
-            atomicAdd(srep + mom * p.Cn + co0 + c, v);
+            vc_stat_add(sums, (unsigned)bx, p.Cn, mom * p.Cn + co0 + c, v);
         }
     }
     // ---- BatchNorm finalize, per co block: the sums of channels [co0, co0 + BCO) are complete when the last of the
@@ -349,11 +347,7 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
     float* sfin = (float*)smem;  // [2][BCO]: sum and sum of squares over the replicas, in replica order
     if (tid_e < 2 * BCO) {
         const int mom = tid_e / BCO, c = co0 + (tid_e - mom * BCO);
-        float v = 0.f;
-#pragma unroll
-        for (int r = 0; r < VC_STAT_REPLICAS; ++r)
-            v += vc_stat_load<true>(sums + (size_t)r * 2 * p.Cn + mom * p.Cn + c);
-        sfin[tid_e] = v;
+        sfin[tid_e] = vc_stat_total<true>(sums, p.Cn, mom * p.Cn + c);
     }
     __syncthreads();
     if (RED) {
@@ -412,6 +406,7 @@ int launch_pw(const VcPwParams& p, hipStream_t stream) {
         });
     }
     VcPwParams q = p;
+    q.stats = vc_det_tag(q.stats), q.red_sums = vc_det_tag(q.red_sums);
     static const bool no_xcd_map = getenv("VC_NO_XCD_MAP") != nullptr || getenv("VC_PW_NO_XCD_MAP") != nullptr;
     q.xcd_map = (grid.y > 1 && !no_xcd_map) ? 1 : 0;
     (void)hipGetLastError();

@@ -314,8 +314,7 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NWAV
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < NWAVE; ++w) s += sred[w * 128 + tid];
-            float* srep = p.stats + (size_t)(blockIdx.x & (VC_STAT_REPLICAS - 1)) * 2 * 64;
-            atomicAdd(srep + (tid < 64 ? 0 : 64) + (tid & 63), s);
+            vc_stat_add(p.stats, blockIdx.x, 64, (tid < 64 ? 0 : 64) + (tid & 63), s);
         }
     }
     vc_bn_fin_last(p.fin, p.stats, 64);
@@ -366,6 +365,7 @@ int vc_stem_fwd_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcSte
 int vc_launch_stem_fwd(VcStemFwdParams& p, hipStream_t stream) {
     static VcPerDeviceOnce once;  // thread-safe, once per device
     once.run([&]() { (void)hipFuncSetAttribute((const void*)stem_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    p.stats = vc_det_tag(p.stats);
     (void)hipGetLastError();
     hipLaunchKernelGGL(stem_fwd_kernel, dim3(p.grid), dim3(NWAVE * 64), p.lds_bytes, stream, p);
     const hipError_t e = hipGetLastError();

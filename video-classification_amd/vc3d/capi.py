@@ -69,6 +69,8 @@ _BF = C.POINTER(BnFin)
 PROTOTYPES = {
     "vc_last_error": [],
     "vc_abi_version": [],
+    "vc_set_deterministic": [_I],
+    "vc_get_deterministic": [],
     "vc_conv3d_out_dims": [_CD, _IP, _IP, _IP],
     "vc_conv3d_workspace_bytes": [_CD, _I],
     "vc_conv3d_fwd": [_CD, _P, _P, _P, _P, _P, C.c_size_t, _P],

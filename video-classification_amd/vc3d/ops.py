@@ -612,3 +612,12 @@ def nthwc_to_ncthw(x, dtype=F32):
     check(lib.vc_nthwc_to_ncthw(ptr(x), ptr(out), 1 if dtype == BF16 else 0, N, Cc, S, cur_stream()),
           "vc_nthwc_to_ncthw")
     return out
+
+
+def set_deterministic(on):
+    """vc_set_deterministic: BatchNorm sums accumulated as exact 64-bit fixed-point integers instead of float atomics
+    (include/vc3d.h): a step's results no longer depend on the order in which workgroups finish.  Process-wide; also
+    VC_DETERMINISTIC=1 in the environment.  Returns the previous setting."""
+    prev = bool(lib.vc_get_deterministic())
+    check(lib.vc_set_deterministic(1 if on else 0), "vc_set_deterministic")
+    return prev
