@@ -26,6 +26,7 @@ SIDE_WGRAD = os.environ.get("VC_WGRAD_SIDE_STREAM", "1") != "0"  # weight gradie
 # gradient it reduces (vc_conv3d_dgrad_fused; VC_NO_BNRED_FOLD=1 in the library runs the two launches instead)
 FOLD_BN_RED = os.environ.get("VC_NO_BNRED") is None
 RELU_BITS = os.environ.get("VC_NO_RELU_BITS") is None  # residual blocks save their ReLU mask as bits (VC_NO_RELU_BITS=1: read the activation instead)
+DS_LAST = os.environ.get("VC_NO_DS_LAST") is None  # strided downsample's data gradient after the block's first conv's
 FIRST_STATS = os.environ.get("VC_FIRST_STATS") is not None  # stand-alone row-0-shifted statistics on a layer's first step
 
 
@@ -570,19 +571,28 @@ class R3DEngine:
                                    coef=icoef, reduced=icoef is not None, frozen=frozen)
                 icoef = None
                 self._ready(cb.bn.weight, cb.bn.bias)
+                # A block with a downsample branch adds two data gradients into the block input's gradient.  Which one
+                # goes first is free; the second accumulates (reads what the first wrote).  A STRIDED 1x1x1 downsample
+                # only touches one input position in st*sh*sw: as the first it costs a memset of the whole gradient and
+                # makes the block's first conv read all of it back (BasicBlock, layer2.0: 9 + 26 us of a 120 us pair);
+                # as the second it reads and rewrites an eighth.  So the first conv goes first unless its own launch is
+                # the dense GEMM that carries the folded reduction (Bottleneck: 1x1x1, unit stride).
+                ds_last = (i == 0 and ds is not None and self.trace is None and DS_LAST and
+                           not (d.kt * d.kh * d.kw == 1 and d.st * d.sh * d.sw == 1))
                 if i == 0 and ds is not None:
-                    # downsample branch first so the first conv's dgrad can accumulate onto it
                     dd, yd, prmd = dsrec
                     dyd, _ = ops.bn_bwd(yd, gres, prmd, ds.Co, self.gview(ds.bn.weight), self.gview(ds.bn.bias),
                                         mask=0, sums=sums_pool.take(ds.Co), ticket=self._bticket(ds), frozen=frozen)
                     self._ready(ds.bn.weight, ds.bn.bias)
                     self._wgrad(dd, xin, dyd, ds.conv)
                     _, wdd = ds.weights()
-                    dzd = gres
-                    gres = ops.conv3d_dgrad(dd, dyd, wdd)
-                    self._t(ds.name, dz=dzd, dy=dyd, dx=gres.clone() if self.trace is not None else None,
-                            dx_base=None)
-                    del dyd
+                    if not ds_last:
+                        # downsample branch first so the first conv's dgrad can accumulate onto it
+                        dzd = gres
+                        gres = ops.conv3d_dgrad(dd, dyd, wdd)
+                        self._t(ds.name, dz=dzd, dy=dyd, dx=gres.clone() if self.trace is not None else None,
+                                dx_base=None)
+                        del dyd
                 self._wgrad(d, h, dy, cb.conv)
                 _, wd = cb.weights()
                 dz_in = dz
@@ -595,7 +605,11 @@ class R3DEngine:
                         _, _, py, pprm, pout = precs[-1]
                         if pout.dtype == torch.uint8:
                             coef, red = red_of(pcbs[-1], py, pprm, pout)
-                    if masked_acc:
+                    if ds_last:
+                        dz = ops.conv3d_dgrad(d, dy, wd)
+                        dz = ops.conv3d_dgrad(dd, dyd, wdd, out=dz, accumulate=True, bnred=red)
+                        del dyd
+                    elif masked_acc:
                         dz = ops.conv3d_dgrad(d, dy, wd, out=g, accumulate=True, bnred=red, acc_bits=out)
                     else:
                         dz = ops.conv3d_dgrad(d, dy, wd, out=gres, accumulate=True, bnred=red)
