@@ -146,6 +146,7 @@ struct VcStemWgradParams {
     int RH, KS;      // output rows per chunk, 32-row k-steps per chunk
     int TR, nhg, ntr, units;  // frames per unit, row groups, frame ranges, units = N * nhg * ntr
     int plane_pieces, grid, lds_bytes;
+    int xcd_map;
 };
 int vc_stem_wgrad_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcStemWgradParams* out);  // 0 = not applicable
 size_t vc_stem_wgrad_slab_bytes(const VcStemWgradParams& p);
@@ -163,6 +164,7 @@ struct VcStemFwdParams {
     int RH;          // output rows per chunk (RH * Wo <= 224)
     int TR, nhg, ntr, units;
     int plane_pieces, grid, lds_bytes;
+    int xcd_map;     // XCD k takes the k-th contiguous eighth of each round of units
 };
 int vc_stem_fwd_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcStemFwdParams* out);  // 0 = not applicable
 int vc_launch_stem_fwd(VcStemFwdParams& p, hipStream_t stream);

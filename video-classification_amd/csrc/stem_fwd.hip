@@ -127,7 +127,12 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(NWAV
         }
     };
 
-    for (int u = blockIdx.x; u < p.units; u += gridDim.x) {
+    // Workgroups are dealt round-robin to the 8 XCDs; neighbouring units share source rows (3 of a row group's RH + 3
+    // rows, 6 of a frame range's TR + 6 frames), so XCD k takes the k-th contiguous eighth of each round of units and
+    // the shared rows are hits in its own L2 (the source was read 2.2x from HBM with the plain order).
+    unsigned bx = blockIdx.x;
+    if (p.xcd_map) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    for (int u = (int)bx; u < p.units; u += gridDim.x) {
         const int tr = u % p.ntr;
         const int hg = (u / p.ntr) % p.nhg;
         const int n = u / (p.ntr * p.nhg);
@@ -358,6 +363,8 @@ int vc_stem_fwd_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcSte
     p.units = N * p.nhg * p.ntr;
     p.grid = p.units < target ? p.units : target;
     p.lds_bytes = NWB * WBUF + 1024 + NSLOT * p.plane_pieces * 1024;
+    static const bool no_xcd = getenv("VC_NO_XCD_MAP") != nullptr || getenv("VC_STEM_NO_XCD_MAP") != nullptr;
+    p.xcd_map = (p.grid % 8 == 0 && p.grid >= 16 && !no_xcd) ? 1 : 0;
     *out = p;
     return 1;
 }

@@ -97,7 +97,9 @@ __global__ __launch_bounds__(NWAVE * 64) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     };
 
-    for (int u = blockIdx.x; u < p.units; u += gridDim.x) {
+    unsigned bx = blockIdx.x;  // XCD k takes the k-th contiguous eighth of each round of units (stem_fwd.hip)
+    if (p.xcd_map) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    for (int u = (int)bx; u < p.units; u += gridDim.x) {
         const int tr = u % p.ntr;
         const int hg = (u / p.ntr) % p.nhg;
         const int n = u / (p.ntr * p.nhg);
@@ -204,6 +206,8 @@ int vc_stem_wgrad_plan(int N, int T, int Ho, int Wo, int Hp, int Wp, int Co, VcS
     p.ntr = ntr;
     p.units = N * p.nhg * ntr;
     p.grid = p.units < target ? p.units : target;
+    static const bool no_xcd = getenv("VC_NO_XCD_MAP") != nullptr || getenv("VC_STEM_NO_XCD_MAP") != nullptr;
+    p.xcd_map = (p.grid % 8 == 0 && p.grid >= 16 && !no_xcd) ? 1 : 0;
     p.lds_bytes = TAB_BYTES + 2 * p.KS * 32 * 128 + 8 * p.plane_pieces * 1024;
     *out = p;
     return 1;
