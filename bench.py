@@ -356,7 +356,7 @@ def main():
             return False
         timed[0] = True
         return True
-    ops.TIMER = ops.KernelTimer(select=pick) if dominant is not None else None
+    ops.TIMER = ops.KernelTimer(select=pick, key=dominant) if dominant is not None else None
     if ddp:
         dist.barrier()
     torch.cuda.synchronize()

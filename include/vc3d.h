@@ -292,6 +292,36 @@ int vc_ncthw_to_nthwc(const void* in, int32_t in_is_bf16, void* out, int32_t N, 
 int vc_nthwc_to_ncthw(const void* in, void* out, int32_t out_is_bf16, int32_t N, int32_t C, int64_t S,
                       void* stream);
 
+/* ---- Command lists: a recorded launch sequence replayed by one call (no counterpart in the reference, whose step is
+ * enqueued layer by layer from Python: lib/core/function.py:71-82).  A command is one call of an entry point of this
+ * library (any one that returns int and takes only integers, pointers and at most VC_CMD_MAX_FLT floats: `fn`, its
+ * integer / pointer arguments in order in iarg, its float arguments in order in farg; descriptor structs are passed by
+ * pointer and must stay alive and unchanged), or a cross-stream dependency: VC_CMD_EVENT_RECORD (iarg[0] = index into
+ * `events`, iarg[1] = stream) / VC_CMD_STREAM_WAIT (same operands: the stream waits for the event).  vc_replay issues
+ * the commands in order, exactly as the recorded calls were issued, and stops at the first failure (*failed_at = its
+ * index, the entry point's message in vc_last_error).  time_cmd >= 0: HIP events time_start / time_stop (created with
+ * timing) are recorded on that command's stream around it.  The caller guarantees what made the recording valid:
+ * every pointer in the list still names the buffer it named.  x86-64 System V only (replay.hip). */
+#define VC_CMD_MAX_INT 16
+#define VC_CMD_MAX_FLT 8
+#define VC_CMD_CALL 0
+#define VC_CMD_EVENT_RECORD 1
+#define VC_CMD_STREAM_WAIT 2
+typedef struct vc_cmd {
+    void* fn;
+    int32_t kind, nint, nflt, pad_;
+    int64_t iarg[VC_CMD_MAX_INT];
+    float farg[VC_CMD_MAX_FLT];
+} vc_cmd;
+int vc_replay(const vc_cmd* cmds, int32_t n, void* const* events, int32_t n_events, int32_t time_cmd /* -1: none */,
+              void* time_start, void* time_stop, int32_t* failed_at /* nullable */);
+int vc_replay_events_create(int32_t n, int32_t timing, void** out);
+int vc_replay_events_destroy(int32_t n, void** events);
+int vc_replay_event_elapsed_ms(void* start, void* stop, float* ms);
+/* small helpers so that a whole step is expressible as commands */
+int vc_memset_async(void* ptr, int32_t value, size_t bytes, void* stream);
+int vc_incr_i64(const void* ptr_table /* device: int64* [n] */, int32_t n, void* stream); /* *ptr[i] += 1 (BatchNorm's num_batches_tracked) */
+
 #ifdef __cplusplus
 }
 #endif

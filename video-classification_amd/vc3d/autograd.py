@@ -13,12 +13,15 @@ from . import ops
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, engine, training, anchor, *params):
+        # `params`: ONE parameter that requires a gradient (or none): it ties this node into the graph so that backward
+        # is called; the gradients themselves are written by the engine, not returned (62 inputs cost autograd ~50 us)
         # `anchor` = whether activations must be kept (grad mode is off inside Function.forward)
         # (eval mode with gradients on keeps the activations too: a backward then runs with frozen BatchNorm statistics,
         # engine._backward; plain inference belongs under torch.no_grad(), which takes the fused inference epilogues)
         feat, saved = engine.forward(x, training, save=bool(anchor))
         ctx.engine = engine
         ctx.saved = saved
+        ctx.n_params = len(params)
         return feat
 
     @staticmethod
@@ -29,7 +32,7 @@ class _BackboneFn(torch.autograd.Function):
         eng._bind_grads()
         eng.backward(ctx.saved, dfeat)
         ctx.saved = None
-        return (None, None, None, None) + (None,) * len(eng._fn_params)
+        return (None, None, None, None) + (None,) * ctx.n_params
 
 
 def backbone_apply(engine, x, training):
@@ -43,7 +46,10 @@ def backbone_apply(engine, x, training):
         from .capi import Vc3dError
         raise Vc3dError("the vc3d backbone does not compute the gradient with respect to the input clip "
                         "(pass the clip without requires_grad)")
-    return _BackboneFn.apply(x, engine, training, need_grad, *params)
+    tie = next((p for p in params if p.requires_grad), None) if need_grad else None
+    if tie is None:
+        return _BackboneFn.apply(x, engine, training, need_grad)
+    return _BackboneFn.apply(x, engine, training, need_grad, tie)
 
 
 class _LinearFn(torch.autograd.Function):

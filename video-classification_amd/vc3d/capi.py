@@ -60,6 +60,14 @@ class BnBwdRed(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("y", "params", "relu_bits", "sums", "ticket", "coef", "dgamma", "dbeta")]
 
 
+class Cmd(C.Structure):
+    """vc_cmd: one recorded call / cross-stream dependency of a command list (include/vc3d.h, vc_replay)."""
+    _fields_ = [("fn", C.c_void_p), ("kind", C.c_int32), ("nint", C.c_int32), ("nflt", C.c_int32), ("pad_", C.c_int32),
+                ("iarg", C.c_int64 * 16), ("farg", C.c_float * 8)]
+
+
+CMD_CALL, CMD_EVENT_RECORD, CMD_STREAM_WAIT = 0, 1, 2
+
 _CD = C.POINTER(ConvDesc)
 _PD = C.POINTER(PoolDesc)
 _IP = C.POINTER(C.c_int32)
@@ -119,6 +127,12 @@ PROTOTYPES = {
     "vc_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vc_ncthw_to_nthwc": [_P, _I, _P, _I, _I, _L, _P],
     "vc_nthwc_to_ncthw": [_P, _P, _I, _I, _I, _L, _P],
+    "vc_replay": [C.POINTER(Cmd), _I, C.POINTER(C.c_void_p), _I, _I, _P, _P, _IP],
+    "vc_replay_events_create": [_I, _I, C.POINTER(C.c_void_p)],
+    "vc_replay_events_destroy": [_I, C.POINTER(C.c_void_p)],
+    "vc_replay_event_elapsed_ms": [_P, _P, C.POINTER(C.c_float)],
+    "vc_memset_async": [_P, _I, C.c_size_t, _P],
+    "vc_incr_i64": [_P, _I, _P],
 }
 _RESTYPE = {"vc_last_error": C.c_char_p, "vc_stem_packed_input_elems": C.c_size_t, "vc_static_scratch_bytes": C.c_size_t,
             "vc_conv3d_workspace_bytes": C.c_size_t, "vc_stem_wgrad_workspace_bytes": C.c_size_t}
@@ -139,7 +153,37 @@ def _load():
     return lib
 
 
-lib = _load()
+_raw = _load()
+
+# The recorder of a command list (vc3d/replay.py) while a step is being recorded, else None.  Every call of an entry
+# point goes through _Lib below: the call is made, and -- while recording -- appended to the list with its arguments.
+RECORDER = None
+_HOST_ONLY = {"vc_abi_version", "vc_conv3d_out_dims", "vc_pool3d_out_dims", "vc_set_deterministic", "vc_get_deterministic",
+              "vc_replay", "vc_replay_events_create", "vc_replay_events_destroy", "vc_replay_event_elapsed_ms"}
+
+
+class _Lib:
+    """libvc3d.so's entry points; `lib.vc_xxx(...)` as with the plain CDLL.  A wrapper per entry point is made on first
+    use and kept in the instance dict, so later attribute lookups do not come back to __getattr__."""
+
+    def __getattr__(self, name):
+        fn = getattr(_raw, name)
+        argtypes = fn.argtypes
+        recordable = fn.restype is C.c_int and name in PROTOTYPES and name not in _HOST_ONLY
+
+        def call(*args):
+            rc = fn(*args)
+            if RECORDER is not None and recordable:
+                RECORDER.add(name, fn, argtypes, args, rc)
+            return rc
+
+        call.__name__ = name
+        call.raw = fn
+        setattr(self, name, call)
+        return call
+
+
+lib = _Lib()
 
 
 def check(rc, what=""):

@@ -10,12 +10,14 @@ gradient is final so its bucket can be all-reduced while the rest of backward ru
 Gradients are written into one flat fp32 buffer (reverse layer order); ``param.grad`` are
 views of it with the parameter's own strides.
 """
+import os
+import weakref
+
 import torch
 
-from . import ops
+from . import capi, ops
 from .capi import VC_STAT_REPLICAS, VC_TICKET_WORDS, Vc3dError
-
-import os
+from .replay import Recorder
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -27,11 +29,22 @@ SIDE_WGRAD = os.environ.get("VC_WGRAD_SIDE_STREAM", "1") != "0"  # weight gradie
 FOLD_BN_RED = os.environ.get("VC_NO_BNRED") is None
 RELU_BITS = os.environ.get("VC_NO_RELU_BITS") is None  # residual blocks save their ReLU mask as bits (VC_NO_RELU_BITS=1: read the activation instead)
 DS_LAST = os.environ.get("VC_NO_DS_LAST") is None  # strided downsample's data gradient after the block's first conv's
+# a training step's launch sequence is recorded once and replayed by one C call per forward and per backward
+# (vc3d/replay.py, csrc/replay.hip); VC_NO_REPLAY=1 keeps every step on the eager path
+REPLAY = os.environ.get("VC_NO_REPLAY") is None
 FIRST_STATS = os.environ.get("VC_FIRST_STATS") is not None  # stand-alone row-0-shifted statistics on a layer's first step
 
 
 def _triple(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+class _TapeStep:
+    """what a recorded forward hands to autograd in place of the saved activations: which step of which recording"""
+    __slots__ = ("tape", "serial", "__weakref__")
+
+    def __init__(self, tape, serial):
+        self.tape, self.serial = tape, serial
 
 
 class _ConvBN:
@@ -101,6 +114,7 @@ class R3DEngine:
         self._tickets = None       # zero int32 words of the fused BatchNorm finalize (see _ticket)
         self._ticket_ix = None
         self.trace = None  # tests set this to {} to record every intermediate tensor per layer
+        self._tape = None  # the recorded training step (command lists + the tensors they name), see _forward_recorded
         # BatchNorm sums are taken relative to the previous batch mean (cb.shift).  On a layer's FIRST training step no
         # such estimate exists: by default the fused sums run with a zero shift (the textbook one-pass form on the fp32
         # accumulators: exact to 1e-5 for |mean| <= 10 sigma, and a bf16 tensor with |mean| = 100 sigma has lost its
@@ -123,6 +137,9 @@ class R3DEngine:
 
     def params_backward_order(self):
         """parameters in the order their gradients become final during backward."""
+        cached = getattr(self, "_pbo", None)
+        if cached is not None:  # the module tree (and so the order) is fixed once the engine exists
+            return cached
         out = []
         for cbs, ds in reversed(self.blocks):
             seq = list(reversed(cbs))
@@ -133,6 +150,7 @@ class R3DEngine:
                 out += [ds.bn.weight, ds.bn.bias, ds.conv.weight]
             out += [seq[-1].bn.weight, seq[-1].bn.bias, seq[-1].conv.weight]
         out += [self.stem.bn.weight, self.stem.bn.bias, self.stem.conv.weight]
+        self._pbo = out
         return out
 
     def setup_grads(self, extra_first=()):
@@ -195,11 +213,16 @@ class R3DEngine:
         """after a fused optimizer step wrote flat_param AND flat_shadow: one launch makes every dgrad
         operand, and every conv's cached operands become views of the flat buffers."""
         ops.pack_dgrad_batched(self.flat_shadow, self.flat_wd, self.wd_table_dev, self.wd_table_host)
-        for cb, off_s, off_d, n in self.wd_ranges:
-            taps = cb.k[0] * cb.k[1] * cb.k[2]
-            cb.wf = self.flat_shadow[off_s:off_s + n].view(cb.Co, taps * cb.Ci)
-            cb.wd = self.flat_wd[off_d:off_d + n].view(cb.Ci, taps * cb.Co)
-            cb.wver = cb.conv.weight._version
+        views = getattr(self, "_wviews", None)
+        if views is None or views[0] is not self.flat_shadow or views[1] is not self.flat_wd:
+            made = []
+            for cb, off_s, off_d, n in self.wd_ranges:  # the views never change: made once per pair of flat buffers
+                taps = cb.k[0] * cb.k[1] * cb.k[2]
+                made.append((cb, self.flat_shadow[off_s:off_s + n].view(cb.Co, taps * cb.Ci),
+                             self.flat_wd[off_d:off_d + n].view(cb.Ci, taps * cb.Co)))
+            views = self._wviews = (self.flat_shadow, self.flat_wd, made)
+        for cb, wf, wd in views[2]:
+            cb.wf, cb.wd, cb.wver = wf, wd, cb.conv.weight._version
         self.param_epoch += 1
 
     def invalidate_weights(self):
@@ -269,8 +292,12 @@ class R3DEngine:
             self._side = torch.cuda.Stream(device=dy.device)
         ev = torch.cuda.Event()
         ev.record()
+        rec = capi.RECORDER
+        rev = rec.event_record(capi.cur_stream()) if rec is not None else None
         with torch.cuda.stream(self._side):
             self._side.wait_event(ev)
+            if rec is not None:
+                rec.stream_wait(capi.cur_stream(), rev)
             ops.conv3d_wgrad(d, h, dy, self._gphys(conv.weight))
             self._ready(conv.weight)  # a bucket all-reduce must wait for THIS stream: the event is recorded here
         dy.record_stream(self._side)  # dy is dropped right after the dgrad on the main stream
@@ -283,6 +310,7 @@ class R3DEngine:
         if self._tickets is None or self._tickets.device != dev:
             self._ticket_ix = {id(c): i for i, c in enumerate(self.all_convbn())}
             self._tickets = torch.zeros(2 * len(self._ticket_ix) * VC_TICKET_WORDS, dtype=torch.int32, device=dev)
+            self._tape = None  # a recorded step names the old words
         i = (2 * self._ticket_ix[id(cb)] + (1 if bwd else 0)) * VC_TICKET_WORDS
         return self._tickets[i:i + VC_TICKET_WORDS]
 
@@ -309,6 +337,7 @@ class R3DEngine:
         if cb.shift is None or cb.shift.device != dev:
             cb.shift = torch.zeros(cb.Co, dtype=F32, device=dev)
             cb.shift_valid = False
+            self._tape = None  # a recorded step names the old buffer
         return cb.shift
 
     def _first_stats(self, cb, y, stats, count):
@@ -370,7 +399,123 @@ class R3DEngine:
             params = self._bn_params(cb, stats, count, training)
         return d, y, params
 
+    # ------------------------------------------------------------------ recorded steps
+    def _bn_signature(self):
+        return tuple((cb.bn.momentum, cb.bn.eps, cb.bn.track_running_stats) for cb in self.all_convbn())
+
+    def _replay_key(self, x, training, save):
+        """the conditions under which a recorded training step stays valid, or None when this call is not a candidate.
+        Everything a recorded command names by address must be persistent: the flat parameter / gradient buffers and
+        the packed weights the fused optimizers maintain, BatchNorm buffers, shifts and tickets, the split-K workspace,
+        and the step's own intermediates (kept alive by the tape)."""
+        if not (REPLAY and training and save) or self.trace is not None or self.first_stats:
+            return None
+        if ops.TIMER is not None and ops.TIMER.select is None:
+            return None  # a step that times every launch runs eagerly
+        if isinstance(x, ops.PackedClips) or not x.is_cuda or x.dim() != 5 or x.shape[1] != 3 or x.dtype not in (F32, BF16):
+            return None
+        if x.shape[3] % 2 or x.shape[4] % 2 or not x.is_contiguous() or x.device.index != torch.cuda.current_device():
+            return None
+        if self.flat_shadow is None or self.flat_grad is None or x.device != self.flat_shadow.device:
+            return None  # torch optimizers repack the weights into fresh tensors every step
+        for cb in self.all_convbn():
+            if cb.bn.training != training:
+                return None
+            if cb is not self.stem and (cb.wf is None or cb.wver != cb.conv.weight._version):
+                return None
+        bn0, bn1 = self.stem.bn, self.blocks[-1][0][-1].bn  # a module moved or re-created takes all its buffers along
+        return (tuple(x.shape), x.dtype, x.device, capi.cur_stream(), self.flat_grad.data_ptr(), self.flat_shadow.data_ptr(),
+                ops.WS_EPOCH, bn0.running_mean.data_ptr() if bn0.running_mean is not None else 0,
+                bn1.running_var.data_ptr() if bn1.running_var is not None else 0, bool(capi.lib.vc_get_deterministic()), self._bn_signature(), FUSED_BN_FIN, FOLD_BN_RED)
+
+    def _forward_recorded(self, x, key):
+        """(features, step token) from the recorded step, or None when this call has to run eagerly."""
+        tape = self._tape
+        if tape is not None and tape["key"] == key:
+            live = tape["live"]() if tape["live"] is not None else None
+            if live is not None:
+                return None  # the recorded step's activations still wait for their backward: this call runs eagerly
+            fwd = tape["fwd"]
+            fwd.patch("x", x.data_ptr())
+            self.stat_epoch += 1
+            pair = tcmd = None
+            tk = getattr(ops.TIMER, "key", None) if ops.TIMER is not None else None
+            if tk is not None and tk in tape["tags"]:
+                tcmd, flops = tape["tags"][tk]
+                pair = ops.TIMER.replay_pair(tk, flops)
+            if pair is not None:
+                fwd.replay(tcmd, pair[0], pair[1])
+            else:
+                fwd.replay()
+            tape["serial"] += 1
+            step = _TapeStep(tape, tape["serial"])
+            tape["live"] = weakref.ref(step)
+            return tape["feat"].detach(), step
+        # record: the step runs as usual, with every launch noted and every intermediate tensor kept alive
+        self._tape = None
+        self.stem_wver = -1  # the stem's weight pack must be part of the recording, whatever was cached
+        tensors, rec = [], Recorder()
+        ops.TAPE, capi.RECORDER = tensors, rec
+        try:
+            feat, saved = self._forward(x, True, True)
+        finally:
+            ops.TAPE, capi.RECORDER = None, None
+        if rec.failed is not None or ops.WS_EPOCH != key[6]:
+            return feat, saved  # (e.g. the split-K workspace grew: the next step records again)
+        fwd = rec.freeze({"x": x.data_ptr()})
+        tape = {"key": key, "fwd": fwd, "bwd": None, "tensors": tensors, "feat": feat, "saved": saved, "serial": 0,
+                "live": None, "tags": {tag[0]: (idx, tag[1]) for tag, idx in fwd.tags.items()}}
+        step = _TapeStep(tape, 0)
+        tape["live"] = weakref.ref(step)
+        self._tape = tape
+        return feat, step
+
+    def _backward_recorded(self, step, dfeat):
+        tape = step.tape
+        if tape["live"] is None or tape["live"]() is not step or step.serial != tape["serial"]:
+            raise Vc3dError("backward of a recorded step whose activations have been overwritten by a later step")
+        tape["live"] = None
+        df = dfeat.contiguous()
+        eager = (tape is not self._tape or self.grad_ready_cb is not None or self.backward_done_cb is not None or
+                 self.trace is not None or (ops.TIMER is not None and ops.TIMER.select is None) or
+                 capi.cur_stream() != tape["key"][3] or self.flat_grad.data_ptr() != tape["key"][4])
+        if eager:
+            # (data-parallel buckets are launched from Python between the kernels: that backward stays eager, the
+            # forward keeps its recording)
+            return self._backward(tape["saved"], df)
+        if tape["bwd"] is not None:
+            tape["bwd"].patch("dfeat", df.data_ptr())
+            tape["bwd"].replay()
+            return None
+        rec = Recorder()
+        ops.TAPE, capi.RECORDER = tape["tensors"], rec
+        try:
+            self._backward(tape["saved"], df)
+        finally:
+            ops.TAPE, capi.RECORDER = None, None
+        if rec.failed is None and ops.WS_EPOCH == tape["key"][6]:
+            tape["bwd"] = rec.freeze({"dfeat": df.data_ptr()})
+        else:
+            self._tape = None
+        return None
+
     def forward(self, x, training, save):
+        key = self._replay_key(x, training, save)
+        if key is not None:
+            try:
+                out = self._forward_recorded(x, key)
+            except Vc3dError:
+                self._tape = None
+                self._reset_tickets()
+                raise
+            except ValueError:  # BatchNorm's one-value refusal while recording (see below)
+                self._tape = None
+                if self._nbt:
+                    torch._foreach_add_(self._nbt, 1)
+                    self._nbt = []
+                raise
+            if out is not None:
+                return out
         try:
             if x.is_cuda and x.device.index != torch.cuda.current_device():
                 with torch.cuda.device(x.device):  # launches go to the current device's stream: make it the clips' device
@@ -387,6 +532,8 @@ class R3DEngine:
 
     def backward(self, saved, dfeat):
         try:
+            if isinstance(saved, _TapeStep):
+                return self._backward_recorded(saved, dfeat)
             return self._backward(saved, dfeat)
         except Vc3dError:
             self._reset_tickets()
@@ -403,6 +550,21 @@ class R3DEngine:
             if t is not None:
                 cb.shift = t.to(device=dev, dtype=F32).clone()
                 cb.shift_valid = True
+        self._tape = None  # recorded steps name the buffers just replaced
+
+    def _count_batches(self):
+        """num_batches_tracked += 1 for the BatchNorm layers of this forward: one launch over a table of their device
+        addresses (a recordable command; torch._foreach_add_ for a list that is not the usual one)."""
+        key = tuple(t.data_ptr() for t in self._nbt)
+        if getattr(self, "_nbt_key", None) != key:
+            if any(t.dtype != torch.int64 or not t.is_cuda for t in self._nbt):
+                if capi.RECORDER is not None:
+                    capi.RECORDER.failed = "BatchNorm step counters that are not int64 device tensors"
+                torch._foreach_add_(self._nbt, 1)
+                return
+            self._nbt_table = torch.tensor(key, dtype=torch.int64).to(self._nbt[0].device)
+            self._nbt_key = key
+        ops.incr_i64(self._nbt_table, len(key))
 
     def _reset_tickets(self):
         """a launch that failed midway may leave ticket words of the fused BatchNorm finalize non-zero (they are only
@@ -500,7 +662,7 @@ class R3DEngine:
                         dd = yd = prmd = None
                         r = xin
                     # the block output's ReLU mask as bits for the backward (it reads 1 bit, not 16, per element)
-                    bits = torch.empty(y.numel() // 8, dtype=torch.uint8, device=y.device) if save and RELU_BITS else None
+                    bits = ops._empty(y.numel() // 8, dtype=torch.uint8, device=y.device) if save and RELU_BITS else None
                     out = ops.bn_apply(y, prm, cb.Co, residual=r, relu=True, relu_bits=bits)
                     recs.append((d, h, y, prm, out if bits is None else bits))
                     dsrec = (dd, yd, prmd)
@@ -509,7 +671,7 @@ class R3DEngine:
                 saved["blocks"].append((xin, recs, dsrec))
             cur = out
         if self._nbt:
-            torch._foreach_add_(self._nbt, 1)  # one launch for all BatchNorm step counters
+            self._count_batches()  # one launch for all BatchNorm step counters
         Nn, To, Ho, Wo, Cf = cur.shape
         feat = ops.gavgpool_fwd(cur, Nn, To * Ho * Wo, Cf)
         self._t("final", x=cur, feat=feat)
@@ -552,7 +714,7 @@ class R3DEngine:
 
             def red_of(pcb, py, pprm, bits):
                 """the reduction of pcb's BatchNorm backward, to ride along with the dgrad that makes its gradient"""
-                c = torch.empty(2, pcb.Co, dtype=F32, device=dev)
+                c = ops._empty(2, pcb.Co, dtype=F32, device=dev)
                 return c, (py, pprm, bits, sums_pool.take(pcb.Co), self._ticket(pcb, True), c,
                            self.gview(pcb.bn.weight), self.gview(pcb.bn.bias))
 
@@ -636,11 +798,16 @@ class R3DEngine:
         self._ready(st.bn.weight, st.bn.bias)
         if self._stem_scratch is None or self._stem_scratch.device != dev or self._stem_scratch.shape[0] != st.Co:
             self._stem_scratch = torch.zeros(st.Co, ops.STEM_K, dtype=F32, device=dev)
+            if capi.RECORDER is None:
+                self._tape = None  # (while recording, the new buffer is the one the commands name)
         self._t("conv1", dy=dy0)
         ops.stem_wgrad(xs, dy0, N, T, H, W, st.Co, self._gphys(st.conv.weight), scratch=self._stem_scratch)
         self._ready(st.conv.weight)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+            rec = capi.RECORDER
+            if rec is not None:
+                rec.stream_wait(capi.cur_stream(), rec.event_record(self._side.cuda_stream))
         if self.backward_done_cb is not None:
             self.backward_done_cb()
 
@@ -649,7 +816,7 @@ class _StatsPool:
     """one zero-filled allocation carved into per-layer [R][2][C] accumulators."""
 
     def __init__(self, total_channels, device):
-        self.buf = torch.zeros(total_channels * 2 * VC_STAT_REPLICAS, dtype=F32, device=device)
+        self.buf = ops.zeros(total_channels * 2 * VC_STAT_REPLICAS, F32, device)
         self.off = 0
 
     def take(self, C):

@@ -17,8 +17,9 @@ class KernelTimer:
     """HIP-event timing of individual launches on the current stream (bench.py / profiling only).
     ``select`` is a predicate on the launch key (kind, shape...); None times every conv launch."""
 
-    def __init__(self, select=None):
+    def __init__(self, select=None, key=None):
         self.select = select
+        self.key = key  # the one launch a REPLAYED step times (engine command lists); select still decides how often
         self.records = {}  # key -> [flops_per_launch, [(start, end), ...]]
 
     def begin(self, key, flops):
@@ -30,16 +31,70 @@ class KernelTimer:
         self.records.setdefault(key, [flops, []])[1].append((e0, e1))
         return e1
 
+    def replay_pair(self, key, flops):
+        """for a REPLAYED step (engine command lists): raw HIP events (start, stop) that vc_replay records around the
+        command of launch `key`, or None when the key is not selected."""
+        if self.select is None or not self.select(key):
+            return None
+        import ctypes
+        evs = (ctypes.c_void_p * 2)()
+        check(lib.vc_replay_events_create(2, 1, evs), "vc_replay_events_create")
+        self.records.setdefault(key, [flops, []])[1].append((evs, None))
+        return evs
+
     def summary(self):
         """{key: (launches, avg_ms, flops_per_launch)}; call after a device synchronize."""
+        import ctypes
         out = {}
         for key, (flops, evs) in self.records.items():
-            ms = [a.elapsed_time(b) for a, b in evs]
+            ms = []
+            for a, b in evs:
+                if b is None:  # a replay pair
+                    v = ctypes.c_float()
+                    check(lib.vc_replay_event_elapsed_ms(a[0], a[1], ctypes.byref(v)), "vc_replay_event_elapsed_ms")
+                    lib.vc_replay_events_destroy(2, a)
+                    ms.append(v.value)
+                else:
+                    ms.append(a.elapsed_time(b))
             out[key] = (len(ms), sum(ms) / max(len(ms), 1), flops)
         return out
 
 
 TIMER = None  # set to a KernelTimer to time conv launches
+
+# While the engine records a step (vc3d/replay.py) every tensor allocated here is appended to TAPE and so stays alive
+# for as long as the recording does: the recorded commands name these buffers by address.
+TAPE = None
+WS_EPOCH = 0  # bumped whenever a split-K workspace is (re)allocated: recorded commands name it by address too
+
+
+def _empty(*shape, dtype, device):
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if TAPE is not None:
+        TAPE.append(t)
+    return t
+
+
+def _empty_like(ref):
+    t = torch.empty_like(ref)
+    if TAPE is not None:
+        TAPE.append(t)
+    return t
+
+
+def zeros(n, dtype, device):
+    """n zeroed elements by an explicit (recordable) memset on the current stream"""
+    t = _empty(n, dtype=dtype, device=device)
+    check(lib.vc_memset_async(t.data_ptr(), 0, t.numel() * t.element_size(), cur_stream()), "vc_memset_async")
+    return t
+
+
+def incr_i64(table, n):
+    """*ptr += 1 for the n device pointers in `table` (int64 tensor on the GPU): BatchNorm's num_batches_tracked"""
+    _chk(table, torch.int64, n, "pointer table")
+    check(lib.vc_incr_i64(table.data_ptr(), n, cur_stream()), "vc_incr_i64")
+
+
 
 
 def _conv_key(kind, d):
@@ -79,6 +134,10 @@ def _workspace(d, op, device, need=None):
     key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < need:
+        global WS_EPOCH
+        WS_EPOCH += 1
+        if capi.RECORDER is not None:  # commands recorded so far name the old buffer: this step cannot be kept
+            capi.RECORDER.failed = "the split-K workspace grew while recording"
         buf = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf.data_ptr(), buf.numel()
@@ -92,7 +151,7 @@ def conv_desc(N, Ci, T, H, W, Co, k, s, p):
 
 
 def new_stats(C, device):
-    return torch.zeros(VC_STAT_REPLICAS, 2, C, dtype=F32, device=device)
+    return zeros(VC_STAT_REPLICAS * 2 * C, F32, device).view(VC_STAT_REPLICAS, 2, C)
 
 
 # ------------------------------------------------------------------ conv
@@ -102,8 +161,8 @@ def pack_weight(w_master, want_dgrad=True):
     wm = w_master.detach().permute(0, 2, 3, 4, 1)  # physical [Co][kt][kh][kw][Ci]
     _chk(wm, F32, name="w_master (channels_last_3d)")
     taps = kt * kh * kw
-    wf = torch.empty(Co, taps * Ci, dtype=BF16, device=wm.device)
-    wd = torch.empty(Ci, taps * Co, dtype=BF16, device=wm.device) if want_dgrad else None
+    wf = _empty(Co, taps * Ci, dtype=BF16, device=wm.device)
+    wd = _empty(Ci, taps * Co, dtype=BF16, device=wm.device) if want_dgrad else None
     check(lib.vc_pack_weight(ptr(wm), ptr(wf), ptr(wd), Co, taps, Ci, cur_stream()), "vc_pack_weight")
     return wf, wd
 
@@ -117,7 +176,7 @@ def bn_fin(ticket, count, gamma, beta, running_mean, running_var, momentum, eps,
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
         _chk(t, F32, Cn, nm)
     if params is None:
-        params = torch.empty(4, Cn, dtype=F32, device=gamma.device)
+        params = _empty(4, Cn, dtype=F32, device=gamma.device)
     _chk(params, F32, 4 * Cn, "bn params")
     _chk(shift, F32, Cn, "bn shift")  # sums relative to it; receives this batch's mean (the next step's shift)
     f = capi.BnFin(ptr(ticket), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(params), float(count),
@@ -134,10 +193,12 @@ def conv3d_fwd(d, x, wf, stats=None, out=None, fin=None, act_params=None, relu=T
     _chk(x, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "x")
     _chk(wf, BF16, d.Co * taps * d.Ci, "w")
     if out is None:
-        out = torch.empty(d.N, To, Ho, Wo, d.Co, dtype=BF16, device=x.device)
+        out = _empty(d.N, To, Ho, Wo, d.Co, dtype=BF16, device=x.device)
     _chk(out, BF16, d.N * To * Ho * Wo * d.Co, "y")
     _chk(stats, F32, VC_STAT_REPLICAS * 2 * d.Co, "bn_stats")
     ev = TIMER.begin(_conv_key("fwd", d), _conv_flops(d)) if TIMER is not None else None
+    if capi.RECORDER is not None:
+        capi.RECORDER.tag = (_conv_key("fwd", d), _conv_flops(d))
     ws, wsb = _workspace(d, 0, x.device)
     if act_params is not None:
         if stats is not None or fin is not None:
@@ -168,9 +229,11 @@ def conv3d_dgrad(d, dy, wd, out=None, accumulate=False, bnred=None, acc_bits=Non
     if out is None:
         if accumulate:
             raise capi.Vc3dError("conv3d_dgrad: accumulate needs an existing dx")
-        out = torch.empty(d.N, d.Ti, d.Hi, d.Wi, d.Ci, dtype=BF16, device=dy.device)
+        out = _empty(d.N, d.Ti, d.Hi, d.Wi, d.Ci, dtype=BF16, device=dy.device)
     _chk(out, BF16, d.N * d.Ti * d.Hi * d.Wi * d.Ci, "dx")
     ev = TIMER.begin(_conv_key("dgrad", d), _conv_flops(d)) if TIMER is not None else None
+    if capi.RECORDER is not None:
+        capi.RECORDER.tag = (_conv_key("dgrad", d), _conv_flops(d))
     ws, wsb = _workspace(d, 1, dy.device)
     if acc_bits is not None and not accumulate:
         raise capi.Vc3dError("conv3d_dgrad: acc_bits needs accumulate")
@@ -206,6 +269,8 @@ def conv3d_wgrad(d, x, dy, dw):
     _chk(dy, BF16, d.N * To * Ho * Wo * d.Co, "dy")
     _chk(dw, F32, d.Co * taps * d.Ci, "dw")
     ev = TIMER.begin(_conv_key("wgrad", d), _conv_flops(d)) if TIMER is not None else None
+    if capi.RECORDER is not None:
+        capi.RECORDER.tag = (_conv_key("wgrad", d), _conv_flops(d))
     ws, wsb = _workspace(d, 2, x.device)
     check(lib.vc_conv3d_wgrad(d, ptr(x), ptr(dy), ptr(dw), ws, wsb, cur_stream()), "vc_conv3d_wgrad")
     if ev is not None:
@@ -268,7 +333,7 @@ def stem_pack_input(x):
     if x.dtype not in (F32, BF16):
         raise capi.Vc3dError("stem input must be fp32 or bf16")
     _chk(x, x.dtype, name="clip")
-    xs = torch.empty(N, T + 6, H // 2 + 3, stem_wp(W), 12, dtype=BF16, device=x.device)
+    xs = _empty(N, T + 6, H // 2 + 3, stem_wp(W), 12, dtype=BF16, device=x.device)
     check(lib.vc_stem_pack_input(ptr(x), 1 if x.dtype == BF16 else 0, ptr(xs), N, T, H, W, cur_stream()),
           "vc_stem_pack_input")
     return xs
@@ -299,7 +364,7 @@ def clip_pack_u8(frames, crops, T, H, W, tstep=1, mean=(0.0, 0.0, 0.0), std=(1.0
     if crops.is_cuda or crops.dtype != torch.int32 or tuple(crops.shape) != (N, 4) or not crops.is_contiguous():
         raise capi.Vc3dError("clip_pack_u8: crops must be a contiguous int32 host tensor of shape N x 4")
     crops_dev = crops.to(frames.device, non_blocking=True)
-    xs = torch.empty(N, T + 6, H // 2 + 3, stem_wp(W), 12, dtype=BF16, device=frames.device)
+    xs = _empty(N, T + 6, H // 2 + 3, stem_wp(W), 12, dtype=BF16, device=frames.device)
     m = (capi.C.c_float * 3)(*[float(v) for v in mean])
     s = (capi.C.c_float * 3)(*[float(v) for v in std])
     check(lib.vc_clip_pack_u8(ptr(frames), ptr(crops_dev), crops.data_ptr(), ptr(xs), N, T, H, W, Ts, Hs, Ws, int(tstep),
@@ -313,7 +378,7 @@ def stem_pack_weight(w_master):
         raise capi.Vc3dError("stem weight must be [Co][3][7][7][7]")
     wm = w_master.detach().permute(0, 2, 3, 4, 1)
     _chk(wm, F32, name="stem w_master (channels_last_3d)")
-    ws = torch.empty(Co, STEM_K, dtype=BF16, device=wm.device)
+    ws = _empty(Co, STEM_K, dtype=BF16, device=wm.device)
     check(lib.vc_stem_pack_weight(ptr(wm), ptr(ws), Co, cur_stream()), "vc_stem_pack_weight")
     return ws
 
@@ -322,11 +387,13 @@ def stem_fwd(xs, ws, N, T, H, W, Co, stats=None, out=None, fin=None):
     _chk(xs, BF16, N * (T + 6) * (H // 2 + 3) * stem_wp(W) * 12, "xs")
     _chk(ws, BF16, Co * STEM_K, "ws")
     if out is None:
-        out = torch.empty(N, T, H // 2, W // 2, Co, dtype=BF16, device=xs.device)
+        out = _empty(N, T, H // 2, W // 2, Co, dtype=BF16, device=xs.device)
     _chk(out, BF16, N * T * (H // 2) * (W // 2) * Co, "y")
     _chk(stats, F32, VC_STAT_REPLICAS * 2 * Co, "bn_stats")
     flops = 2.0 * N * T * (H // 2) * (W // 2) * Co * 1029
     ev = TIMER.begin(("stem_fwd", N, T, H, W, Co), flops) if TIMER is not None else None
+    if capi.RECORDER is not None:
+        capi.RECORDER.tag = (("stem_fwd", N, T, H, W, Co), flops)
     if fin is not None:
         check(lib.vc_stem_fwd_bn(ptr(xs), ptr(ws), ptr(out), ptr(stats), fin, N, T, H, W, Co, cur_stream()),
               "vc_stem_fwd_bn")
@@ -346,9 +413,12 @@ def stem_wgrad(xs, dy, N, T, H, W, Co, dw_master_phys, scratch=None):
         scratch = torch.zeros(Co, STEM_K, dtype=F32, device=xs.device)
     else:
         _chk(scratch, F32, Co * STEM_K, "stem wgrad scratch")
-        scratch.zero_()
+        # (an explicit memset call, not scratch.zero_(): a recorded step replays entry points of the library only)
+        check(lib.vc_memset_async(scratch.data_ptr(), 0, scratch.numel() * 4, cur_stream()), "vc_memset_async")
     flops = 2.0 * N * T * (H // 2) * (W // 2) * Co * 1029
     ev = TIMER.begin(("stem_wgrad", N, T, H, W, Co), flops) if TIMER is not None else None
+    if capi.RECORDER is not None:
+        capi.RECORDER.tag = (("stem_wgrad", N, T, H, W, Co), flops)
     ws, wsb = _workspace(None, 2, xs.device, need=int(lib.vc_stem_wgrad_workspace_bytes(N, T, H, W, Co)))
     check(lib.vc_stem_wgrad(ptr(xs), ptr(dy), ptr(scratch), N, T, H, W, Co, ws, wsb, cur_stream()), "vc_stem_wgrad")
     if ev is not None:
@@ -378,7 +448,7 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
         _chk(t, F32, Cn, nm)
     if params is None:
-        params = torch.empty(4, Cn, dtype=F32, device=gamma.device)
+        params = _empty(4, Cn, dtype=F32, device=gamma.device)
     _chk(params, F32, 4 * Cn, "bn params")
     _chk(shift, F32, Cn, "bn shift")
     _chk(shift_next, F32, Cn, "bn shift_next")
@@ -393,7 +463,7 @@ def bn_eval_params(gamma, beta, running_mean, running_var, eps, params=None):
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
         _chk(t, F32, Cn, nm)
     if params is None:
-        params = torch.empty(4, Cn, dtype=F32, device=gamma.device)
+        params = _empty(4, Cn, dtype=F32, device=gamma.device)
     _chk(params, F32, 4 * Cn, "bn params")
     check(lib.vc_bn_eval_params(Cn, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps),
                                 ptr(params), cur_stream()), "vc_bn_eval_params")
@@ -407,7 +477,7 @@ def bn_apply(y, params, C, residual=None, relu=True, out=None, relu_bits=None):
     _chk(params, F32, 4 * C, "bn params")
     _chk(residual, BF16, y.numel(), "residual")
     if out is None:
-        out = torch.empty_like(y)
+        out = _empty_like(y)
     _chk(out, BF16, y.numel(), "out")
     if relu_bits is not None:
         if not relu:
@@ -447,13 +517,13 @@ def bn_bwd(y, dz, params, C, gamma_grad, beta_grad, mask=0, aux=None, want_g=Fal
         sums = new_stats(C, y.device)
     _chk(sums, F32, VC_STAT_REPLICAS * 2 * C, "sums")
     if coef is None:
-        coef = torch.empty(2, C, dtype=F32, device=y.device)
+        coef = _empty(2, C, dtype=F32, device=y.device)
     _chk(coef, F32, 2 * C, "coef")
     if dy is None:
-        dy = torch.empty_like(y)
+        dy = _empty_like(y)
     _chk(dy, BF16, n, "dy")
     if want_g and g_out is None:
-        g_out = torch.empty_like(y)
+        g_out = _empty_like(y)
     _chk(g_out, BF16, n, "g_out")
     s = cur_stream()
     if reduced:
@@ -495,8 +565,8 @@ def bn_bwd_pooled(pd, y, dpooled, idx, params, C, gamma_grad, beta_grad, sums=No
     if sums is None:
         sums = new_stats(C, y.device)
     _chk(sums, F32, VC_STAT_REPLICAS * 2 * C, "sums")
-    coef = torch.empty(2, C, dtype=F32, device=y.device)
-    dy = torch.empty_like(y)
+    coef = _empty(2, C, dtype=F32, device=y.device)
+    dy = _empty_like(y)
     s = cur_stream()
     if ticket is not None:
         _chk(ticket, torch.int32, capi.VC_TICKET_WORDS, "ticket")
@@ -519,7 +589,7 @@ def add(a, b, out=None):
     _chk(a, BF16, name="a")
     _chk(b, BF16, a.numel(), "b")
     if out is None:
-        out = torch.empty_like(a)
+        out = _empty_like(a)
     _chk(out, BF16, a.numel(), "out")
     check(lib.vc_add(ptr(a), ptr(b), ptr(out), a.numel(), cur_stream()), "vc_add")
     return out
@@ -537,8 +607,8 @@ def maxpool3d_fwd(d, y, bn_params=None):
     To, Ho, Wo = d.out_dims()
     _chk(y, BF16, d.N * d.T * d.H * d.W * d.C, "y")
     _chk(bn_params, F32, 4 * d.C, "bn params")
-    out = torch.empty(d.N, To, Ho, Wo, d.C, dtype=BF16, device=y.device)
-    idx = torch.empty(d.N, To, Ho, Wo, d.C, dtype=torch.uint8, device=y.device)
+    out = _empty(d.N, To, Ho, Wo, d.C, dtype=BF16, device=y.device)
+    idx = _empty(d.N, To, Ho, Wo, d.C, dtype=torch.uint8, device=y.device)
     check(lib.vc_maxpool3d_fwd(d, ptr(y), ptr(bn_params), ptr(out), ptr(idx), cur_stream()), "vc_maxpool3d_fwd")
     return out, idx
 
@@ -547,21 +617,21 @@ def maxpool3d_bwd(d, dout, idx):
     To, Ho, Wo = d.out_dims()
     _chk(dout, BF16, d.N * To * Ho * Wo * d.C, "dout")
     _chk(idx, torch.uint8, d.N * To * Ho * Wo * d.C, "argmax")
-    din = torch.empty(d.N, d.T, d.H, d.W, d.C, dtype=BF16, device=dout.device)
+    din = _empty(d.N, d.T, d.H, d.W, d.C, dtype=BF16, device=dout.device)
     check(lib.vc_maxpool3d_bwd(d, ptr(dout), ptr(idx), ptr(din), cur_stream()), "vc_maxpool3d_bwd")
     return din
 
 
 def gavgpool_fwd(x, N, S, Cn):
     _chk(x, BF16, N * S * Cn, "x")
-    out = torch.empty(N, Cn, dtype=F32, device=x.device)
+    out = _empty(N, Cn, dtype=F32, device=x.device)
     check(lib.vc_gavgpool_fwd(ptr(x), ptr(out), N, S, Cn, cur_stream()), "vc_gavgpool_fwd")
     return out
 
 
 def gavgpool_bwd(dfeat, N, S, Cn, shape):
     _chk(dfeat, F32, N * Cn, "dfeat")
-    din = torch.empty(shape, dtype=BF16, device=dfeat.device)
+    din = _empty(shape, dtype=BF16, device=dfeat.device)
     _chk(din, BF16, N * S * Cn, "din")
     check(lib.vc_gavgpool_bwd(ptr(dfeat), ptr(din), N, S, Cn, cur_stream()), "vc_gavgpool_bwd")
     return din
@@ -573,7 +643,7 @@ def linear_fwd(feat, W, bias):
     _chk(feat, F32, name="feat")
     _chk(W, F32, K * Fd, "W")
     _chk(bias, F32, K, "bias")
-    out = torch.empty(N, K, dtype=F32, device=feat.device)
+    out = _empty(N, K, dtype=F32, device=feat.device)
     check(lib.vc_linear_fwd(ptr(feat), ptr(W), ptr(bias), ptr(out), N, Fd, K, cur_stream()), "vc_linear_fwd")
     return out
 
@@ -586,7 +656,7 @@ def linear_bwd(dlogits, feat, W, dW=None, db=None, want_dfeat=True):
     _chk(W, F32, K * Fd, "W")
     _chk(dW, F32, K * Fd, "dW")
     _chk(db, F32, K, "db")
-    dfeat = torch.empty(N, Fd, dtype=F32, device=dlogits.device) if want_dfeat else None
+    dfeat = _empty(N, Fd, dtype=F32, device=dlogits.device) if want_dfeat else None
     check(lib.vc_linear_bwd(ptr(dlogits), ptr(feat), ptr(W), ptr(dfeat), ptr(dW), ptr(db), N, Fd, K, cur_stream()),
           "vc_linear_bwd")
     return dfeat
@@ -598,7 +668,7 @@ def ncthw_to_nthwc(x):
     if x.dtype not in (F32, BF16):
         raise capi.Vc3dError("layout: fp32 or bf16 only")
     _chk(x, x.dtype, name="x")
-    out = torch.empty((N,) + tuple(x.shape[2:]) + (Cc,), dtype=BF16, device=x.device)
+    out = _empty((N,) + tuple(x.shape[2:]) + (Cc,), dtype=BF16, device=x.device)
     check(lib.vc_ncthw_to_nthwc(ptr(x), 1 if x.dtype == BF16 else 0, ptr(out), N, Cc, S, cur_stream()),
           "vc_ncthw_to_nthwc")
     return out
@@ -608,7 +678,7 @@ def nthwc_to_ncthw(x, dtype=F32):
     N, Cc = x.shape[0], x.shape[-1]
     S = x.numel() // (N * Cc)
     _chk(x, BF16, name="x")
-    out = torch.empty((N, Cc) + tuple(x.shape[1:-1]), dtype=dtype, device=x.device)
+    out = _empty((N, Cc) + tuple(x.shape[1:-1]), dtype=dtype, device=x.device)
     check(lib.vc_nthwc_to_ncthw(ptr(x), ptr(out), 1 if dtype == BF16 else 0, N, Cc, S, cur_stream()),
           "vc_nthwc_to_ncthw")
     return out

@@ -31,10 +31,12 @@ class _FlatOptimizer(torch.optim.Optimizer):
         dev = head[0].device
         if eng.flat_grad is None or eng.flat_grad.device != dev:
             eng.setup_grads(extra_first=head)
-        known = {id(p) for p in eng.plist}
-        for p in self.param_groups[0]["params"]:
-            if id(p) not in known:
-                raise Vc3dError("%s: a parameter is not part of the engine's flat buffer" % type(self).__name__)
+        if getattr(self, "_known_for", None) is not eng.plist:  # checked once per flat-buffer layout
+            known = {id(p) for p in eng.plist}
+            for p in self.param_groups[0]["params"]:
+                if id(p) not in known:
+                    raise Vc3dError("%s: a parameter is not part of the engine's flat buffer" % type(self).__name__)
+            self._known_for = eng.plist
         if eng.flat_shadow is None:
             eng.setup_flat_weights()
         for p in eng.plist:  # gradients that did not come from the engine's backward: move them in
