@@ -35,9 +35,30 @@ struct VcBnBwdFin {  // backward: sums (sum g, sum g*xhat) -> coef [2][C]; dgamm
 };
 
 template <bool AGENT>
+__device__ __forceinline__ float vc_stat_load(const float* p) {
+    return AGENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+// The float-replica form, branch-free: all 2 x VC_STAT_REPLICAS loads of a channel (and, in the batched tails below, of
+// several channels) are in flight at once.  With the mode test inside, the compiler cannot hoist the loads across it
+// and the last workgroup's tail becomes a chain of dependent round trips below the L2 (R3D-50's 2048-channel
+// downsample conv: 42 -> 206 us) -- so the callers test the mode ONCE and take this path or the deterministic one.
+template <bool AGENT>
+__device__ __forceinline__ void vc_stat_sum_f(const float* stats, int C, int c, float& s, float& q) {
+    s = 0.f, q = 0.f;
+#pragma unroll
+    for (int r = 0; r < VC_STAT_REPLICAS; ++r) {
+        s += vc_stat_load<AGENT>(stats + (size_t)r * 2 * C + c);
+        q += vc_stat_load<AGENT>(stats + (size_t)r * 2 * C + C + c);
+    }
+}
+template <bool AGENT>
 __device__ __forceinline__ void vc_stat_sum(const float* stats, int C, int c, float& s, float& q) {
-    s = vc_stat_total<AGENT>(stats, C, c);      // common.h: float replicas in replica order, or the deterministic limbs
-    q = vc_stat_total<AGENT>(stats, C, C + c);
+    if (vc_stat_is_det(stats)) {
+        s = vc_stat_total_det(stats, C, c, AGENT);
+        q = vc_stat_total_det(stats, C, C + c, AGENT);
+    } else {
+        vc_stat_sum_f<AGENT>(stats, C, c, s, q);
+    }
 }
 
 template <bool AGENT>
@@ -136,6 +157,12 @@ __device__ __forceinline__ void vc_bn_fin_last(const VcBnFin& f, const float* st
                                          f.eps, f.params, f.shift, f.shift_out);
         return;
     }
+    if (vc_stat_is_det(stats)) {  // deterministic mode: the plain per-channel loop (no batching needed for a debug mode)
+        for (int c = threadIdx.x; c < C; c += blockDim.x)
+            vc_bn_finalize_channel<true>(stats, C, c, f.count, f.gamma, f.beta, f.running_mean, f.running_var, f.momentum,
+                                         f.eps, f.params, f.shift, f.shift_out);
+        return;
+    }
     const int step = (int)blockDim.x;
 #pragma clang loop unroll(disable)  // unrolled, this tail sets the whole kernel's register allocation (and occupancy)
     for (int base = (int)threadIdx.x; base < C; base += step * VC_FIN_BATCH) {
@@ -146,7 +173,7 @@ __device__ __forceinline__ void vc_bn_fin_last(const VcBnFin& f, const float* st
             const int c = base + k * step;
             s[k] = q[k] = g[k] = b[k] = rm[k] = rv[k] = sh[k] = 0.f;
             if (c < C) {
-                vc_stat_sum<true>(stats, C, c, s[k], q[k]);
+                vc_stat_sum_f<true>(stats, C, c, s[k], q[k]);
                 g[k] = f.gamma[c], b[k] = f.beta[c];
                 if (f.running_mean != nullptr) rm[k] = f.running_mean[c], rv[k] = f.running_var[c];
                 if (f.shift != nullptr) sh[k] = f.shift[c];
@@ -184,6 +211,11 @@ __device__ __forceinline__ void vc_bn_bwd_fin_last(const VcBnBwdFin& f, const fl
             vc_bn_bwd_finalize_channel<true>(sums, C, c, f.count, f.coef, f.dgamma, f.dbeta);
         return;
     }
+    if (vc_stat_is_det(sums)) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x)
+            vc_bn_bwd_finalize_channel<true>(sums, C, c, f.count, f.coef, f.dgamma, f.dbeta);
+        return;
+    }
     const int step = (int)blockDim.x;
 #pragma clang loop unroll(disable)  // unrolled, this tail sets the whole kernel's register allocation (and occupancy)
     for (int base = (int)threadIdx.x; base < C; base += step * VC_FIN_BATCH) {
@@ -193,7 +225,7 @@ __device__ __forceinline__ void vc_bn_bwd_fin_last(const VcBnBwdFin& f, const fl
             const int c = base + k * step;
             s[k] = q[k] = dg[k] = db[k] = 0.f;
             if (c < C) {
-                vc_stat_sum<true>(sums, C, c, s[k], q[k]);
+                vc_stat_sum_f<true>(sums, C, c, s[k], q[k]);
                 if (f.dgamma != nullptr) dg[k] = f.dgamma[c];
                 if (f.dbeta != nullptr) db[k] = f.dbeta[c];
             }

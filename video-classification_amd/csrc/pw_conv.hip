@@ -347,7 +347,15 @@ __global__ __launch_bounds__(256, WPE) void pw_kernel(const VcPwParams p) {
     float* sfin = (float*)smem;  // [2][BCO]: sum and sum of squares over the replicas, in replica order
     if (tid_e < 2 * BCO) {
         const int mom = tid_e / BCO, c = co0 + (tid_e - mom * BCO);
-        sfin[tid_e] = vc_stat_total<true>(sums, p.Cn, mom * p.Cn + c);
+        float v = 0.f;
+        if (vc_stat_is_det(sums)) {
+            v = vc_stat_total_det(sums, p.Cn, mom * p.Cn + c, true);
+        } else {
+#pragma unroll
+            for (int r = 0; r < VC_STAT_REPLICAS; ++r)
+                v += vc_stat_load<true>(sums + (size_t)r * 2 * p.Cn + mom * p.Cn + c);
+        }
+        sfin[tid_e] = v;
     }
     __syncthreads();
     if (RED) {
