@@ -52,8 +52,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", type=int, default=None,
-                    help="ResNet depth; default: 18 on one GPU (BASELINE config 2), 50 on several (config 3, the "
-                         "data-parallel headline)")
+                    help="ResNet depth; default 18 at every N (BASELINE config 2, weak-scaled: one workload along the "
+                         "1/2/4/8 curve, so that value(N) / (N * value(1)) is a scaling efficiency); 50 = config 3")
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--clip-len", type=int, default=16)
     ap.add_argument("--crop", type=int, default=112)
@@ -268,7 +268,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     if args.model is None:
-        args.model = 18 if world == 1 else 50
+        args.model = 18  # the same workload at every N: a scaling curve compares like with like
     if ddp and dist.get_world_size() != world:
         raise SystemExit("bench.py: the process group has %d ranks, WORLD_SIZE says %d" % (dist.get_world_size(), world))
 
