@@ -557,7 +557,10 @@ __global__ __launch_bounds__(256) void maxpool_bn_tiled_kernel(const bf16x8* __r
         sh[k] = params[3 * g.C + cg * 8 + k];
     }
     // per-thread constants of the plane loop (no divisions or 64-bit multiplies inside it: the loop is VALU-bound)
-    bf16x8 ldA[MAXV], ldB[MAXV];  // two planes of loads in flight (one left HBM at 2.5 TB/s: too few bytes in flight per CU)
+    // two planes of loads in flight (one left HBM at 2.5 TB/s: too few bytes in flight per CU).  Held as plain dwords: a
+    // __bf16 vector that lives across the predicated loads below is "repacked" half by half at every merge point
+    // (v_lshrrev + v_perm_b32 per dword, 900 of this kernel's 2700 instructions, and the kernel is VALU-bound)
+    u32x4 ldA[MAXV], ldB[MAXV];
     int src_off[MAXV];  // vector offset inside an input plane; -1: nothing to stage
 #pragma unroll
     for (int u = 0; u < MAXV; ++u) {
@@ -568,19 +571,19 @@ __global__ __launch_bounds__(256) void maxpool_bn_tiled_kernel(const bf16x8* __r
     }
     const bf16x8* yplane = y + (long)n * g.T * g.H * rowv;
     const long plane_stride = (long)g.H * rowv;
-    auto fetch = [&](bf16x8 (&ld)[MAXV]) {
+    auto fetch = [&](u32x4 (&ld)[MAXV]) {
 #pragma unroll
         for (int u = 0; u < MAXV; ++u)
-            if (src_off[u] >= 0) ld[u] = yplane[src_off[u]];
+            if (src_off[u] >= 0) ld[u] = *(const u32x4*)&yplane[src_off[u]];
         yplane += plane_stride;
     };
-    auto stage = [&](int buf, const bf16x8 (&ld)[MAXV]) {
+    auto stage = [&](int buf, const u32x4 (&ld)[MAXV]) {
         bf16x8* dst = sZ + buf * 3 * rowv + threadIdx.x;
 #pragma unroll
         for (int u = 0; u < MAXV; ++u) {
             if (src_off[u] >= 0) {
                 float f[8];
-                unpack8(ld[u], f);
+                unpack8(__builtin_bit_cast(bf16x8, ld[u]), f);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const float v = f[k] * sc[k] + sh[k];
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(256) void maxpool_bn_tiled_kernel(const bf16x8* __r
             *(uint64_t*)(idx + e * 8) = packed;
         }
     };
-    auto plane = [&](int t, bf16x8 (&ld)[MAXV]) {
+    auto plane = [&](int t, u32x4 (&ld)[MAXV]) {
         const int buf = t & 1;
         stage(buf, ld);
         __syncthreads();
@@ -634,7 +637,11 @@ __global__ __launch_bounds__(256) void maxpool_bn_tiled_kernel(const bf16x8* __r
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
             if (wo_[o] >= g.Wo) continue;  // threads beyond the row only stage
-            const bool okw[3] = {okw0[o], true, okw2[o]};
+            // one v_perm_b32 per key: bytes (bits.hi, bits.lo, 0, tap byte) picked from {v, lb}; a column outside the
+            // image selects four zero bytes instead (key 0, below every valid key)
+            const unsigned selw[3][2] = {{okw0[o] ? 0x05040c00u : 0x0c0c0c0cu, okw0[o] ? 0x07060c00u : 0x0c0c0c0cu},
+                                         {0x05040c00u, 0x07060c00u},
+                                         {okw2[o] ? 0x05040c00u : 0x0c0c0c0cu, okw2[o] ? 0x07060c00u : 0x0c0c0c0cu}};
             unsigned kp[8];  // in-plane maximum with tap byte 255 - j (kt = 0)
 #pragma unroll
             for (int k = 0; k < 8; ++k) kp[k] = 0u;
@@ -647,13 +654,8 @@ __global__ __launch_bounds__(256) void maxpool_bn_tiled_kernel(const bf16x8* __r
                     const unsigned lb = 255u - (unsigned)(b * 3 + c);
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        unsigned k0 = (v[m] << 16) | lb, k1 = (v[m] & 0xffff0000u) | lb;
-                        if (c != 1) {
-                            k0 = okw[c] ? k0 : 0u;
-                            k1 = okw[c] ? k1 : 0u;
-                        }
-                        kp[2 * m] = max(kp[2 * m], k0);
-                        kp[2 * m + 1] = max(kp[2 * m + 1], k1);
+                        kp[2 * m] = max(kp[2 * m], __builtin_amdgcn_perm(v[m], lb, selw[c][0]));
+                        kp[2 * m + 1] = max(kp[2 * m + 1], __builtin_amdgcn_perm(v[m], lb, selw[c][1]));
                     }
                 }
             }
@@ -1016,6 +1018,103 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pooled_tiled_kernel(const bf
                 __builtin_nontemporal_store(pack8(o), &drow[w * groups + cg]);
             }
         }
+    }
+}
+
+// The tiled pass with every y load of the workgroup issued up front (NT trips of 256 / groups columns per parity and
+// row: 8 NT 16-byte loads per thread in flight before the pooled rows are staged).  The loop form above has one load
+// per thread in flight (7 waves per SIMD x 16 B: ~7 MB over the chip, under what 2 us of HBM latency wants at 5 TB/s).
+template <int NT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pooled_pf_kernel(const bf16x8* __restrict__ y,
+                                                                     const bf16x8* __restrict__ dout,
+                                                                     const uint8_t* __restrict__ idx,
+                                                                     const float* __restrict__ params,
+                                                                     const float* __restrict__ coef,
+                                                                     bf16x8* __restrict__ dy, VcPoolGeom g, int nbt, int nbh) {
+    extern __shared__ __attribute__((aligned(16))) char pool_sm[];
+    const int C = g.C, groups = C >> 3;
+    const int prow = g.Wo * groups;
+    bf16x8* sD = (bf16x8*)pool_sm;                                // [2][2][prow]
+    uint64_t* sI = (uint64_t*)(pool_sm + (size_t)4 * prow * 16);  // [2][2][prow]
+    unsigned bid = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
+    const int bh = (int)bid % nbh;
+    const int q = (int)bid / nbh;
+    const int bt = q % nbt, n = q / nbt;
+    const int a = bt - 1, b = bh - 1;
+    const int cg = threadIdx.x % groups;
+    const int per_row = g.W * groups;
+    const int half = 256 / groups;
+    const int jw0 = threadIdx.x / groups;
+    bf16x8 yv[4][2][NT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = 2 * a + 1 + (r >> 1), h = 2 * b + 1 + (r & 1);
+        if (t < 0 || t >= g.T || h < 0 || h >= g.H) continue;  // uniform
+        const bf16x8* yrow = y + (((long)n * g.T + t) * g.H + h) * per_row;
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int w = 2 * (u * half + jw0) + par;
+                if (w < g.W) yv[r][par][u] = __builtin_nontemporal_load(&yrow[w * groups + cg]);
+            }
+    }
+    for (int s = 0; s < 4; ++s) {
+        const int to = a + (s >> 1), ho = b + (s & 1);
+        if (to < 0 || to >= g.To || ho < 0 || ho >= g.Ho) continue;  // uniform
+        const long base = (((long)n * g.To + to) * g.Ho + ho) * prow;
+        for (int i = threadIdx.x; i < prow; i += 256) {
+            sD[s * prow + i] = dout[base + i];
+            sI[s * prow + i] = *(const uint64_t*)(idx + (base + i) * 8);
+        }
+    }
+    BnBwdCoef kc;
+    load_bwd_coef(kc, params, coef, C, cg * 8);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = 2 * a + 1 + (r >> 1), h = 2 * b + 1 + (r & 1);
+        if (t < 0 || t >= g.T || h < 0 || h >= g.H) continue;  // uniform
+        const bool todd = (r >> 1) == 0, hodd = (r & 1) == 0;
+        const bool tv[2] = {todd && a >= 0 && a < g.To, a + 1 < g.To}, hv[2] = {hodd && b >= 0 && b < g.Ho, b + 1 < g.Ho};
+        const int tt[2] = {2, todd ? 0 : 1}, ht[2] = {2, hodd ? 0 : 1};
+        bf16x8* drow = dy + (((long)n * g.T + t) * g.H + h) * per_row;
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int jw = u * half + jw0;
+                const int w = 2 * jw + par;
+                if (w >= g.W) continue;
+                float d[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] = 0.f;
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int ih = 0; ih < 2; ++ih) {
+                        if (!tv[it] || !hv[ih]) continue;  // uniform
+                        const int slot = (it * 2 + ih) * prow + cg;
+                        const int tap = (tt[it] * 3 + ht[ih]) * 3;
+                        if (par == 0) {
+                            if (jw < g.Wo) pool_match8(d, sI[slot + jw * groups], sD[slot + jw * groups], tap + 1);
+                        } else {
+                            if (jw < g.Wo) pool_match8(d, sI[slot + jw * groups], sD[slot + jw * groups], tap + 2);
+                            if (jw + 1 < g.Wo)
+                                pool_match8(d, sI[slot + (jw + 1) * groups], sD[slot + (jw + 1) * groups], tap);
+                        }
+                    }
+                float f[8], o[8];
+                unpack8(yv[r][par][u], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float gk = (f[k] * kc.scale[k] + kc.shift[k]) > 0.f ? d[k] : 0.f;
+                    const float xhat = (f[k] - kc.mean[k]) * kc.invstd[k];
+                    o[k] = kc.scale[k] * (gk - kc.c1[k] - xhat * kc.c2[k]);
+                }
+                __builtin_nontemporal_store(pack8(o), &drow[w * groups + cg]);
+            }
     }
 }
 
@@ -1760,8 +1859,17 @@ int vc_ew_bn_bwd_apply_pooled(const void* y, const void* dout, const uint8_t* id
     const bool rowwise = getenv("VC_POOL_BWD_ROWWISE") != nullptr;  // the row-at-a-time kernel (A/B runs, tests)
     if (ref_pool && !rowwise && groups <= 256 && 256 % groups == 0 && lds <= 64 * 1024) {
         const int nbt = (g.T >> 1) + 1, nbh = (g.H >> 1) + 1;
-        VC_LAUNCH(bn_bwd_apply_pooled_tiled_kernel, dim3((unsigned)(g.N * nbt * nbh)), dim3(256), lds, s, (const bf16x8*)y,
-                  (const bf16x8*)dout, idx, params, coef, (bf16x8*)dy, g, nbt, nbh);
+        const int trips = ((g.W + 1) / 2 + 256 / groups - 1) / (256 / groups);  // per parity and row
+        const dim3 grid((unsigned)(g.N * nbt * nbh));
+        if (trips == 1 && getenv("VC_POOL_BWD_NO_PF") == nullptr)
+            VC_LAUNCH(bn_bwd_apply_pooled_pf_kernel<1>, grid, dim3(256), lds, s, (const bf16x8*)y, (const bf16x8*)dout, idx,
+                      params, coef, (bf16x8*)dy, g, nbt, nbh);
+        else if (trips == 2 && getenv("VC_POOL_BWD_NO_PF") == nullptr)
+            VC_LAUNCH(bn_bwd_apply_pooled_pf_kernel<2>, grid, dim3(256), lds, s, (const bf16x8*)y, (const bf16x8*)dout, idx,
+                      params, coef, (bf16x8*)dy, g, nbt, nbh);
+        else
+            VC_LAUNCH(bn_bwd_apply_pooled_tiled_kernel, grid, dim3(256), lds, s, (const bf16x8*)y, (const bf16x8*)dout, idx,
+                      params, coef, (bf16x8*)dy, g, nbt, nbh);
         return VC_CHECK_LAUNCH();
     }
     VC_LAUNCH(bn_bwd_apply_pooled_kernel, dim3(nrows < 4096 ? nrows : 4096), dim3(256), 0, s, (const bf16x8*)y,
