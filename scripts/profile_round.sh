@@ -25,7 +25,16 @@ step "other configs" && {
   timeout -k 10 300 python3 bench.py --model 18 --eval --no-cpu-baseline 2>/dev/null
   timeout -k 10 400 python3 bench.py --model 50 --clip-len 64 --crop 224 --classes 400 --batch 32 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null
   timeout -k 10 400 python3 bench.py --model 50 --clip-len 64 --crop 224 --classes 400 --batch 64 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null
+  # config 5 as specified: 30 views (10 clips x 3 crops) per video through valid.py's loader and validate()
+  timeout -k 10 300 python3 bench.py --model 18 --eval --views 30 --no-cpu-baseline 2>/dev/null
+  timeout -k 10 300 python3 bench.py --model 50 --classes 400 --eval --views 30 --no-cpu-baseline 2>/dev/null
+  # the reference's default optimizer; the deterministic-reduction mode; the RCCL bucket path on one rank
+  timeout -k 10 300 python3 bench.py --optimizer adam --no-cpu-baseline 2>/dev/null
+  VC_DETERMINISTIC=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline 2>/dev/null
+  VC_DDP_FORCE_COMM=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null
 } > $O/bench_other_configs.jsonl
-step "host enqueue" && timeout -k 10 200 python3 scripts/cpu_enqueue.py > $O/cpu_enqueue.txt 2>&1
+step "host enqueue" && { timeout -k 10 200 python3 scripts/cpu_enqueue.py 18 && timeout -k 10 200 python3 scripts/cpu_enqueue.py 50; } > $O/cpu_enqueue.txt 2>&1
+step "timeline" && timeout -k 10 300 rocprofv3 --kernel-trace -d $O/tl -o p -- python3 bench.py --steps 10 --warmup 10 --no-cpu-baseline > $O/tl.log 2>&1 && python3 scripts/step_timeline.py $O/tl/p_results.db > $O/step_timeline.txt
+rm -rf $O/tl
 rm -rf $O/trace18 $O/trace50 gpurun_out/pmc_$TAG/*/p_results.db gpurun_out/pmc_${TAG}_r50/*/p_results.db 2>/dev/null
 ls $O
