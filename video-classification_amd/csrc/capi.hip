@@ -110,7 +110,8 @@ static int conv_max_batch(const vc_conv3d_desc* d, int To, int Ho, int Wo) {
 
 static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const void* w, void* out, float* stats,
                     const VcBnFin* fin, const float* ep_params, int ep_relu, const void* ep_res,
-                    int accumulate, void* workspace, size_t ws_bytes, void* stream);
+                    int accumulate, void* workspace, size_t ws_bytes, void* stream,
+                    const vc_bn_bwd_red* red = nullptr, bool* folded = nullptr);
 
 extern "C" {
 
@@ -448,9 +449,27 @@ int vc_conv3d_fwd_noalloc(const vc_conv3d_desc* d, const void* x, const void* w,
 
 }  // extern "C"
 
+// the split-K finalize of a data gradient takes the BatchNorm backward reduction over the finished gradient along
+// (vc_ew_splitk_finalize_red) when the caller asked for one: *folded reports it.  VC_NO_FINRED=1: separate launches.
+static bool finred_on() {
+    static const bool off = getenv("VC_NO_FINRED") != nullptr;
+    return !off;
+}
+static int finalize_dgrad(const float* slabs, int splits, long long stride, void* dx, int accumulate, long rows, int C,
+                          const vc_bn_bwd_red* red, bool* folded, void* stream) {
+    if (red != nullptr && folded != nullptr && finred_on()) {
+        *folded = true;
+        return vc_ew_splitk_finalize_red(slabs, splits, stride, dx, accumulate, rows, C, red->y, red->params, red->relu_bits,
+                                         red->sums, VcBnBwdFin{red->ticket, red->coef, red->dgamma, red->dbeta, (float)rows},
+                                         S(stream));
+    }
+    return vc_ew_splitk_finalize(slabs, splits, stride, dx, accumulate, nullptr, rows, C, nullptr, S(stream));
+}
+
 static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const void* w, void* out, float* stats,
                     const VcBnFin* fin, const float* ep_params, int ep_relu, const void* ep_res,
-                    int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+                    int accumulate, void* workspace, size_t ws_bytes, void* stream,
+                    const vc_bn_bwd_red* red, bool* folded) {
     VcHaloPlan plan;
     if (halo_plan(d, dgrad, &plan)) {
         vc_set_error("conv3d: no halo tiling fits (H=%d W=%d)", d->Hi, d->Wi);
@@ -473,6 +492,9 @@ static int halo_run(const vc_conv3d_desc* d, bool dgrad, const void* src, const 
         p.stats = nullptr;
         int rc = vc_launch_halo(p, plan, S(stream));
         if (rc) return rc;
+        if (dgrad && stats == nullptr && ep_params == nullptr)
+            return finalize_dgrad(p.partial, plan.splits, p.partial_stride, out, accumulate, (long)(out_e / p.Cn), p.Cn, red,
+                                  folded, stream);
         rc = vc_ew_splitk_finalize(p.partial, plan.splits, p.partial_stride, out, accumulate, stats,
                                    (long)(out_e / p.Cn), p.Cn, stats ? fin : nullptr, S(stream));
         if (rc || ep_params == nullptr) return rc;
@@ -530,7 +552,10 @@ static int conv3d_dgrad_impl(const vc_conv3d_desc* d, const void* dy, const void
     }
     // (3x3x3 stride-1: the halo kernel.  Folding the reduction into its copy-out as well measured no gain -- its
     // epilogue is exposed, and the extra y reads cost it what the separate pass costs -- so `red` runs as a launch there.)
-    if (halo_ok(d)) return halo_run(d, true, dy, w_dgrad, dx, nullptr, nullptr, nullptr, 0, nullptr, accumulate, workspace, ws_bytes, stream);
+    // (with split-K slabs the reduction rides in the finalize launch instead: halo_run / finalize_dgrad)
+    if (halo_ok(d))
+        return halo_run(d, true, dy, w_dgrad, dx, nullptr, nullptr, nullptr, 0, nullptr, accumulate, workspace, ws_bytes, stream,
+                        acc_bits == nullptr ? red : nullptr, folded);
     const int ntaps_all = d->kt * d->kh * d->kw;
     const size_t dx_e = (size_t)d->N * d->Ti * d->Hi * d->Wi * d->Ci;
     int splits = dgrad_splits(d);
@@ -651,8 +676,8 @@ static int conv3d_dgrad_impl(const vc_conv3d_desc* d, const void* dy, const void
         if (rc) return rc;
     }
     if (splits > 1)
-        return vc_ew_splitk_finalize((const float*)workspace, splits, (long long)dx_e, dx, accumulate, nullptr,
-                                     (long)(dx_e / d->Ci), d->Ci, nullptr, S(stream));
+        return finalize_dgrad((const float*)workspace, splits, (long long)dx_e, dx, accumulate, (long)(dx_e / d->Ci), d->Ci,
+                              acc_bits == nullptr ? red : nullptr, folded, stream);
     return 0;
 }
 

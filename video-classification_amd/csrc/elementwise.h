@@ -32,6 +32,9 @@ int vc_ew_bn_bwd_apply(const void* y, const void* dz, const void* aux, const flo
                        void* gout, long n, int C, int mask, hipStream_t s);
 int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void* out, int accumulate, float* stats,
                           long rows, int C, const VcBnFin* fin, hipStream_t s);
+int vc_ew_splitk_finalize_red(const float* slabs, int splits, long long stride, void* out, int accumulate, long rows, int C,
+                              const void* y, const float* params, const uint8_t* bits, float* sums,
+                              const VcBnBwdFin& fin, hipStream_t s);
 // live: bit t set = tap t of the [Co][taps][Ci] gradient was computed (entries of dropped taps are skipped); taps = 0: all
 int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, int Ci, int taps,
                               unsigned live, hipStream_t s);

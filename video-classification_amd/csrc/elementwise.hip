@@ -208,11 +208,21 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const bf16x8* __restri
 // ------------------------------------------------------------------ split-K finalize
 // sum the fp32 slabs of a split-K conv -> bf16 activation (optionally += the existing value)
 // and, optionally, the BatchNorm sum / sum-of-squares of the unrounded result.
-template <bool STATS>
+// STATS 0: nothing more; 1: BatchNorm sums of the result (forward); 2 / 3: the BatchNorm BACKWARD sums (sum g, sum g*xhat,
+// chan_reduce_kernel MODE 1) of the BatchNorm that consumes the finished gradient next, with the ReLU mask recomputed
+// from its y (2) or read from relu bits (3) -- the small-plane data gradients (layers 3-4) are chains of short
+// launches, and this one replaces finalize + reduce (6 + 12 us at 1 k rows) by one pass.
+struct VcFinRed {
+    const bf16x8* y;
+    const float* params;
+    const uint8_t* bits;
+    VcBnBwdFin fin;
+};
+template <int STATS>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ slabs, int splits,
                                                               long long stride, bf16x8* __restrict__ out,
                                                               int accumulate, float* stats, long rows, int C,
-                                                              int CS, VcBnFin fin, const float* stat_shift) {
+                                                              int CS, VcBnFin fin, const float* stat_shift, VcFinRed red) {
     // same decomposition as chan_reduce_kernel: 64-channel slice x row phase (float atomics per launch = RS x 2C)
     __shared__ float sm[STATS ? 256 * 17 : 1];
     const int groups = C >> 3;
@@ -223,7 +233,17 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         a0[k] = a1[k] = 0.f;
-        sh0[k] = (STATS && stat_shift != nullptr) ? stat_shift[g * 8 + k] : 0.f;  // shifted sums (bn_fin.h)
+        sh0[k] = (STATS == 1 && stat_shift != nullptr) ? stat_shift[g * 8 + k] : 0.f;  // shifted sums (bn_fin.h)
+    }
+    float mean[8], invstd[8], scale[8], shift[8];
+    if (STATS >= 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            mean[k] = red.params[g * 8 + k];
+            invstd[k] = red.params[C + g * 8 + k];
+            scale[k] = red.params[2 * C + g * 8 + k];
+            shift[k] = red.params[3 * C + g * 8 + k];
+        }
     }
     for (long row = (long)rs * 32 + r; row < rows; row += (long)RS * 32) {
         const long i = row * groups + g;
@@ -263,13 +283,28 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] += o[k];
         }
-        out[i] = pack8(v);
-        if (STATS) {
+        const bf16x8 ov = pack8(v);
+        out[i] = ov;
+        if (STATS == 1) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float u = v[k] - sh0[k];
                 a0[k] += u;
                 a1[k] += u * u;
+            }
+        }
+        if (STATS >= 2) {  // over the ROUNDED gradient: what the separate reduction reads back
+            float d[8], f[8];
+            unpack8(ov, d);
+            unpack8(red.y[i], f);
+            const unsigned mb = STATS == 3 ? red.bits[i] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float gk = d[k];
+                if (STATS == 2) gk = (f[k] * scale[k] + shift[k]) > 0.f ? gk : 0.f;
+                if (STATS == 3) gk = ((mb >> k) & 1u) ? gk : 0.f;
+                a0[k] += gk;
+                a1[k] += gk * (f[k] - mean[k]) * invstd[k];
             }
         }
     }
@@ -287,7 +322,8 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
             for (int rr = 0; rr < 32; ++rr) s += sm[(rr * 8 + gg) * 17 + k];
             vc_stat_add(stats, (unsigned)rs, C, (k < 8 ? 0 : C) + (cs * 8 + gg) * 8 + (k & 7), s);
         }
-        vc_bn_fin_last(fin, stats, C);
+        if (STATS == 1) vc_bn_fin_last(fin, stats, C);
+        else vc_bn_bwd_fin_last(red.fin, stats, C);
     }
 }
 
@@ -1633,11 +1669,29 @@ int vc_ew_splitk_finalize(const float* slabs, int splits, long long stride, void
     chan_reduce_geometry(rows, C, grid, slices);
     stats = vc_det_tag(stats);
     if (stats)
-        VC_LAUNCH((splitk_finalize_kernel<true>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
-                  accumulate, stats, rows, C, slices, fin ? *fin : VcBnFin{}, fin ? fin->shift : (const float*)nullptr);
+        VC_LAUNCH((splitk_finalize_kernel<1>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
+                  accumulate, stats, rows, C, slices, fin ? *fin : VcBnFin{}, fin ? fin->shift : (const float*)nullptr,
+                  VcFinRed{});
     else
-        VC_LAUNCH((splitk_finalize_kernel<false>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
-                  accumulate, stats, rows, C, slices, VcBnFin{}, (const float*)nullptr);
+        VC_LAUNCH((splitk_finalize_kernel<0>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
+                  accumulate, stats, rows, C, slices, VcBnFin{}, (const float*)nullptr, VcFinRed{});
+    return VC_CHECK_LAUNCH();
+}
+// the finalize of a split-K DATA gradient with the BatchNorm backward reduction over the finished gradient folded in
+// (= vc_ew_splitk_finalize without stats, then vc_ew_bn_bwd_reduce(y, out, bits, params, sums, rows, C, bits ? 3 : 2, fin))
+int vc_ew_splitk_finalize_red(const float* slabs, int splits, long long stride, void* out, int accumulate, long rows, int C,
+                              const void* y, const float* params, const uint8_t* bits, float* sums,
+                              const VcBnBwdFin& fin, hipStream_t s) {
+    int grid, slices;
+    chan_reduce_geometry(rows, C, grid, slices);
+    sums = vc_det_tag(sums);
+    const VcFinRed red{(const bf16x8*)y, params, bits, fin};
+    if (bits != nullptr)
+        VC_LAUNCH((splitk_finalize_kernel<3>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
+                  accumulate, sums, rows, C, slices, VcBnFin{}, (const float*)nullptr, red);
+    else
+        VC_LAUNCH((splitk_finalize_kernel<2>), dim3(grid), dim3(256), 0, s, slabs, splits, stride, (bf16x8*)out,
+                  accumulate, sums, rows, C, slices, VcBnFin{}, (const float*)nullptr, red);
     return VC_CHECK_LAUNCH();
 }
 int vc_ew_splitk_reduce_wgrad(const float* slabs, int splits, long long stride, float* dw, long n, int Ci, int taps,
