@@ -864,7 +864,8 @@ def test_dgrad_with_folded_bn_backward_reduction(geom, accumulate, use_bits):
     vc_bn_bwd_reduce_fin with the ReLU bits (mask mode 3) or with the mask recomputed from y (mode 2, no residual): the
     same dx bit for bit, and coef / dgamma / dbeta equal to the order of the float additions (both reduce the ROUNDED
     dx).  `geom` = the conv (Co -> its input Ci = the BatchNorm's channels).  The 3x3x3 ones take the halo kernel
-    (plain and split-K plans): the entry point runs them as the two launches itself.  accumulate == "masked": the
+    (plain and split-K plans): the entry point runs the plain plans as the two launches itself and, with split-K slabs,
+    takes the reduction in the slab finalize launch (splitk_finalize_kernel<2|3>).  accumulate == "masked": the
     existing dx counts only where its own ReLU bit is set (acc_relu_bits: the identity shortcut's gradient), against
     masking it first with torch."""
     _need_gpu()
