@@ -117,8 +117,57 @@ static void net(int depth, int N, int T, int HW) {
     note(vc_linear_fwd(F, F, F, F, N, cin, 400, nullptr));
 }
 
+// Command lists (vc_replay): the generic call must hand integer AND float arguments to the entry point exactly as a
+// direct call does.  Without a device both forms fail at the launch, after the argument checks: the same return code
+// and the same message show that every argument arrived in its place (a misplaced float would trip "bad arguments"
+// or change the refusal).  Malformed lists are refused with the index of the offending command.
+static int replay_checks() {
+    void* P = (void*)(uintptr_t)0x10000;
+    float* F = (float*)P;
+    auto msg = []() { const char* m = vc_last_error(); return std::string(m ? m : ""); };
+    // direct: floats interleaved with pointers (count, momentum, eps), 10 integer-class arguments (4 of them on the stack)
+    const int rc_direct = vc_bn_finalize(F, 64, 128.f, F, F, nullptr, nullptr, 0.1f, 1e-5f, F, nullptr, nullptr, nullptr);
+    const std::string m_direct = msg();
+    vc_cmd c[4];
+    memset(c, 0, sizeof(c));
+    c[0].fn = (void*)&vc_set_deterministic, c[0].kind = VC_CMD_CALL, c[0].nint = 1, c[0].iarg[0] = 1;
+    c[1].fn = (void*)&vc_set_deterministic, c[1].kind = VC_CMD_CALL, c[1].nint = 1, c[1].iarg[0] = 0;
+    c[2].fn = (void*)&vc_bn_finalize, c[2].kind = VC_CMD_CALL, c[2].nint = 10, c[2].nflt = 3;
+    const int64_t ia[10] = {(int64_t)(uintptr_t)F, 64, (int64_t)(uintptr_t)F, (int64_t)(uintptr_t)F, 0, 0, (int64_t)(uintptr_t)F, 0, 0, 0};
+    for (int i = 0; i < 10; ++i) c[2].iarg[i] = ia[i];
+    c[2].farg[0] = 128.f, c[2].farg[1] = 0.1f, c[2].farg[2] = 1e-5f;
+    c[3] = c[0];
+    int32_t at = -7;
+    const int rc = vc_replay(c, 4, nullptr, 0, -1, nullptr, nullptr, &at);
+    if (rc_direct == 0 || rc != rc_direct || at != 2 || msg() != m_direct) {
+        printf("replay: direct rc %d '%s' vs replayed rc %d at %d '%s'\n", rc_direct, m_direct.c_str(), rc, at, msg().c_str());
+        return 1;
+    }
+    if (vc_get_deterministic() != 0) return 1;  // commands 0 and 1 ran, command 3 (after the failure) did not
+    // a wrong float would be seen: count <= 0 is refused before the launch with another message
+    c[2].farg[0] = 0.f;
+    if (vc_replay(c, 3, nullptr, 0, -1, nullptr, nullptr, &at) != -2 || at != 2 || msg() == m_direct) return 1;
+    // malformed lists
+    vc_cmd bad[1];
+    memset(bad, 0, sizeof(bad));
+    bad[0].kind = VC_CMD_CALL;  // null function
+    if (vc_replay(bad, 1, nullptr, 0, -1, nullptr, nullptr, &at) != -2 || at != 0) return 1;
+    bad[0].fn = (void*)&vc_set_deterministic, bad[0].nint = VC_CMD_MAX_INT + 1;
+    if (vc_replay(bad, 1, nullptr, 0, -1, nullptr, nullptr, &at) != -2 || at != 0) return 1;
+    bad[0].nint = 0, bad[0].kind = 77;  // unknown kind
+    if (vc_replay(bad, 1, nullptr, 0, -1, nullptr, nullptr, &at) != -2 || at != 0) return 1;
+    bad[0].kind = VC_CMD_EVENT_RECORD, bad[0].iarg[0] = 3;  // event 3 of 0
+    if (vc_replay(bad, 1, nullptr, 0, -1, nullptr, nullptr, &at) != -2 || at != 0) return 1;
+    if (vc_replay(nullptr, 0, nullptr, 0, -1, nullptr, nullptr, &at) != 0 || at != -1) return 1;  // the empty list
+    if (vc_replay(nullptr, 2, nullptr, 0, -1, nullptr, nullptr, &at) != -2) return 1;
+    if (vc_memset_async(nullptr, 0, 16, nullptr) != -2 || vc_memset_async(nullptr, 0, 0, nullptr) != 0) return 1;
+    if (vc_incr_i64(nullptr, 4, nullptr) != -2 || vc_incr_i64(nullptr, 0, nullptr) != 0) return 1;
+    return 0;
+}
+
 int main() {
     if (vc_abi_version() != VC_ABI_VERSION) return 2;
+    if (replay_checks() != 0) return 3;
     const int depths[3] = {18, 34, 50};
     for (int depth : depths) {
         net(depth, 64, 16, 112);  // BASELINE configs 1-3

@@ -292,7 +292,10 @@ def test_c_abi_host_code_under_sanitizers():
     every conv / stem / pool / BatchNorm entry point of include/vc3d.h for the R3D-18/34/50 layer geometries at the
     BASELINE clip sizes, a ragged clip, the T = 1 reference geometry and the refused shapes (tests/abi_host_check.cpp).
     There is no GPU here: every launch fails with a message after its host-side set-up has run; the check is that no
-    call crashes and neither sanitizer reports (UBSan is built to abort).  First run builds the binary (~20 s)."""
+    call crashes and neither sanitizer reports (UBSan is built to abort).  The same program replays a command list
+    (vc_replay) whose entry point takes floats between its pointers and more integer arguments than registers, and
+    requires the replayed call to fail exactly as the direct call does (same code, same message: every argument arrived in
+    its place), plus the refusals of malformed lists.  First run builds the binary (~20 s)."""
     import shutil
     import subprocess
     if shutil.which("make") is None or not os.path.exists("/opt/rocm/bin/hipcc"):

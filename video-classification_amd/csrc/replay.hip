@@ -98,6 +98,9 @@ int vc_replay_event_elapsed_ms(void* start, void* stop, float* ms) {
     return 0;
 }
 
+// (no_sanitize("function"): calling through vc_generic_fn is outside the C++ standard by design -- it is the documented
+// behaviour of the platform ABI named above that this relies on; UBSan's function-type check would flag every command)
+__attribute__((no_sanitize("function")))
 int vc_replay(const vc_cmd* cmds, int32_t n, void* const* events, int32_t n_events, int32_t time_cmd, void* time_start,
               void* time_stop, int32_t* failed_at) {
     if (failed_at != nullptr) *failed_at = -1;
