@@ -10,7 +10,7 @@ from helpers import make_config
 pytestmark = pytest.mark.gpu
 
 
-def _train(depth, classes, shapes, replay, opt_name="sgd", double_forward_at=None):
+def _train(depth, classes, shapes, replay, opt_name="sgd", double_forward_at=None, single_stream_at=None):
     import vc3d.engine as eng_mod
     from core.loss import Loss
     from models.model import create_model
@@ -26,6 +26,10 @@ def _train(depth, classes, shapes, replay, opt_name="sgd", double_forward_at=Non
         for i, shape in enumerate(shapes):
             x = torch.randn(*shape, generator=g).to(torch.bfloat16 if (i // 4) % 2 == 0 else torch.float32).cuda()  # a new tensor every step
             y = torch.randint(0, classes, (shape[0],), generator=g).cuda()
+            # (bench.py's timing step: everything on one stream, weight gradients and downsample branches in line)
+            if single_stream_at == i:
+                from vc3d import ops
+                ops.TIMER, eng_mod.SIDE_WGRAD = ops.KernelTimer(), False
             if double_forward_at == i:  # a second forward while the first one's activations wait for their backward
                 _, s2, _ = model(x)
                 l2 = crit(s2, y, None, None)
@@ -38,14 +42,22 @@ def _train(depth, classes, shapes, replay, opt_name="sgd", double_forward_at=Non
             loss.backward()
             opt.step()
             losses.append(loss.detach().clone())
+            if single_stream_at == i:
+                torch.cuda.synchronize()
+                assert len(ops.TIMER.summary()) > 10
+                ops.TIMER, eng_mod.SIDE_WGRAD = None, True
             t = model.backbone.engine._tape
             used.append(None if t is None else (t["fwd"].n, None if t["bwd"] is None else t["bwd"].n, t["serial"]))
         torch.cuda.synchronize()
         eng = model.backbone.engine
         bufs = torch.cat([b.detach().double().flatten() for b in model.buffers()])
-        return torch.stack(losses), eng.flat_grad.clone(), eng.flat_param.clone(), bufs, used
+        nbt = [int(m.num_batches_tracked) for m in model.modules() if isinstance(m, torch.nn.BatchNorm3d)]
+        return torch.stack(losses), eng.flat_grad.clone(), eng.flat_param.clone(), bufs, used, nbt
     finally:
         eng_mod.REPLAY = keep
+        eng_mod.SIDE_WGRAD = True
+        from vc3d import ops as _ops
+        _ops.TIMER = None
 
 
 def _same(a, b):
@@ -103,6 +115,20 @@ def test_replay_with_one_input_format_replays_and_counts_batches(det_mode):
     torch.cuda.synchronize()
     assert bool(torch.isfinite(loss)) and int(model.backbone.bn1.num_batches_tracked) == 9
     assert model.backbone.engine._tape["serial"] == 1
+
+
+def test_a_single_stream_step_between_replays_leaves_no_stale_state(det_mode):
+    """bench.py times every launch in one warm-up step with the side streams off; that step meets the BatchNorm layers
+    in another order (downsample branches in line), which once replaced the table of step counters that the recorded
+    forward names by address -- the next replay then read freed memory.  Steps before, at and after such a step must
+    equal the all-eager run with the same schedule, and every counter must have advanced once per step."""
+    shapes = [(4, 3, 4, 32, 32)] * 8
+    eager = _train(18, 6, shapes, False, single_stream_at=2)
+    rep = _train(18, 6, shapes, True, single_stream_at=2)
+    _same(eager, rep)
+    # step 1 records, step 2 is the eager single-stream step (the recording stays), step 3 REPLAYS the recording of step 1
+    assert [u and u[2] for u in rep[4]] == [None, 0, 0, 1, 0, 1, 2, 3], rep[4]
+    assert len(rep[5]) == 20 and set(rep[5]) == {8} and eager[5] == rep[5], rep[5]
 
 
 def test_second_forward_before_backward_runs_eagerly_and_matches(det_mode):

@@ -28,6 +28,7 @@ SIDE_WGRAD = os.environ.get("VC_WGRAD_SIDE_STREAM", "1") != "0"  # weight gradie
 # gradient it reduces (vc_conv3d_dgrad_fused; VC_NO_BNRED_FOLD=1 in the library runs the two launches instead)
 FOLD_BN_RED = os.environ.get("VC_NO_BNRED") is None
 RELU_BITS = os.environ.get("VC_NO_RELU_BITS") is None  # residual blocks save their ReLU mask as bits (VC_NO_RELU_BITS=1: read the activation instead)
+SIDE_DS = os.environ.get("VC_NO_SIDE_DS") is None  # a block's downsample branch runs beside its main branch (forward)
 DS_LAST = os.environ.get("VC_NO_DS_LAST") is None  # strided downsample's data gradient after the block's first conv's
 # a training step's launch sequence is recorded once and replayed by one C call per forward and per backward
 # (vc3d/replay.py, csrc/replay.hip); VC_NO_REPLAY=1 keeps every step on the eager path
@@ -399,6 +400,33 @@ class R3DEngine:
             params = self._bn_params(cb, stats, count, training)
         return d, y, params
 
+    def _ds_forward_on_side_stream(self, ds, xin, training, stats_pool):
+        """conv + BatchNorm + apply of a downsample branch on the side stream, behind an event on the current one.
+        Returns (desc, y, params, residual, torch event, recorder event) -- the caller waits for the event before it
+        reads the residual.  Tensors made here belong to the side stream's allocator pool and are used on the main
+        stream afterwards (record_stream); the split-K workspace is per stream (ops._workspace)."""
+        main = torch.cuda.current_stream()
+        if self._side is None or self._side.device != xin.device:
+            self._side = torch.cuda.Stream(device=xin.device)
+        ev0 = torch.cuda.Event()
+        ev0.record()
+        rec = capi.RECORDER
+        rev0 = rec.event_record(capi.cur_stream()) if rec is not None else None
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev0)
+            if rec is not None:
+                rec.stream_wait(capi.cur_stream(), rev0)
+            dd, yd, prmd = self._conv_bn(ds, xin, training, stats_pool)
+            r = ops.bn_apply(yd, prmd, ds.Co, relu=False)
+            ev = torch.cuda.Event()
+            ev.record()
+            rev = rec.event_record(capi.cur_stream()) if rec is not None else None
+        xin.record_stream(self._side)
+        for t in (yd, prmd, r):
+            if t is not None:
+                t.record_stream(main)
+        return dd, yd, prmd, r, ev, rev
+
     # ------------------------------------------------------------------ recorded steps
     def _bn_signature(self):
         return tuple((cb.bn.momentum, cb.bn.eps, cb.bn.track_running_stats) for cb in self.all_convbn())
@@ -426,7 +454,8 @@ class R3DEngine:
         bn0, bn1 = self.stem.bn, self.blocks[-1][0][-1].bn  # a module moved or re-created takes all its buffers along
         return (tuple(x.shape), x.dtype, x.device, capi.cur_stream(), self.flat_grad.data_ptr(), self.flat_shadow.data_ptr(),
                 ops.WS_EPOCH, bn0.running_mean.data_ptr() if bn0.running_mean is not None else 0,
-                bn1.running_var.data_ptr() if bn1.running_var is not None else 0, bool(capi.lib.vc_get_deterministic()), self._bn_signature(), FUSED_BN_FIN, FOLD_BN_RED)
+                bn1.running_var.data_ptr() if bn1.running_var is not None else 0, bool(capi.lib.vc_get_deterministic()), self._bn_signature(), FUSED_BN_FIN, FOLD_BN_RED,
+                SIDE_WGRAD, SIDE_DS, DS_LAST)
 
     def _forward_recorded(self, x, key):
         """(features, step token) from the recorded step, or None when this call has to run eagerly."""
@@ -555,7 +584,9 @@ class R3DEngine:
     def _count_batches(self):
         """num_batches_tracked += 1 for the BatchNorm layers of this forward: one launch over a table of their device
         addresses (a recordable command; torch._foreach_add_ for a list that is not the usual one)."""
-        key = tuple(t.data_ptr() for t in self._nbt)
+        # (sorted: the table does not depend on the order in which this forward met its BatchNorm layers -- a step with
+        # the downsample branches on the side stream lists them earlier than one without)
+        key = tuple(sorted(t.data_ptr() for t in self._nbt))
         if getattr(self, "_nbt_key", None) != key:
             if any(t.dtype != torch.int64 or not t.is_cuda for t in self._nbt):
                 if capi.RECORDER is not None:
@@ -564,6 +595,8 @@ class R3DEngine:
                 return
             self._nbt_table = torch.tensor(key, dtype=torch.int64).to(self._nbt[0].device)
             self._nbt_key = key
+            if capi.RECORDER is None:
+                self._tape = None  # a recorded step names the old table (while recording, the new one is the one named)
         ops.incr_i64(self._nbt_table, len(key))
 
     def _reset_tickets(self):
@@ -645,6 +678,13 @@ class R3DEngine:
                 r = act(ds, xin, False) if ds is not None else xin
                 cur = act(cbs[-1], h, True, residual=r)
                 continue
+            # The downsample branch (1x1x1 conv + BatchNorm of the block input) depends on nothing the main branch
+            # computes: it goes to the side stream when the block starts and is joined where the residual is added.
+            # Both branches are short launches that leave most of the GPU idle in layers 2-4 (strided convs on tiny
+            # planes), so they overlap almost for free.
+            side_ds = ds is not None and SIDE_DS and SIDE_WGRAD and training and self.trace is None
+            if side_ds:
+                dsrec_side = self._ds_forward_on_side_stream(ds, xin, training, stats_pool)
             for i, cb in enumerate(cbs):
                 last = (i == len(cbs) - 1)
                 d, y, prm = self._conv_bn(cb, h, training, stats_pool)
@@ -654,7 +694,12 @@ class R3DEngine:
                     self._t(cb.name, x=h, y=y, prm=prm, out=z, res=None, relu=True)
                     h = z
                 else:
-                    if ds is not None:
+                    if side_ds:
+                        dd, yd, prmd, r, ev, rev = dsrec_side
+                        torch.cuda.current_stream().wait_event(ev)
+                        if rev is not None:
+                            capi.RECORDER.stream_wait(capi.cur_stream(), rev)
+                    elif ds is not None:
                         dd, yd, prmd = self._conv_bn(ds, xin, training, stats_pool)
                         r = ops.bn_apply(yd, prmd, ds.Co, relu=False)
                         self._t(ds.name, x=xin, y=yd, prm=prmd, out=r, res=None, relu=False)
