@@ -728,44 +728,49 @@ int vc_halo_plan(int NP, int T, int H, int W, int Cs, int Cn, int ntaps, VcHaloP
                 // segments that are whole (h) rows, whole planes, or an even split of a plane
                 if (!(SEG == HW || SEG % W == 0 || HW % SEG == 0)) continue;
                 if (pad && (SEG % W != 0 || HW % SEG != 0)) continue;  // padded form: whole h-rows, no ragged last segment
-                int TT = BM / SEG;
-                if (TT > NP) TT = NP;
-                if (pad) {
-                    if (TT > T) TT = T;
-                    while (TT > 1 && T % TT != 0) --TT;  // a tile must not straddle two samples
-                }
-                if (TT < 1) continue;
-                const int HR = pad ? (SEG / W + 2) * (W + 1) + 1 : SEG + 2 * W + 2;
-                const int rows = (TT + 2) * HR;
-                const int npieces = (rows + PR - 1) / PR;
-                const int lds = halo_lds(NW, CK, npieces, NB);
-                if (lds > 160 * 1024) continue;
-                if (CK == 32 && 2 * lds > 160 * 1024) continue;  // the 32-channel forms exist for two workgroups per CU
-                const int wgcu = (NW == 4 && 2 * lds <= 160 * 1024) ? 2 : 1;
-                const long tiles = (long)((NP + TT - 1) / TT) * ((HW + SEG - 1) / SEG);
-                for (int splits = 1; splits <= nchunks; splits *= 2) {
-                    const int cps = (nchunks + splits - 1) / splits;
-                    const long wgs = tiles * (Cn / 64) * splits;
-                    const long rounds = (wgs + 256L * wgcu - 1) / (256L * wgcu);
-                    double per_tap, fill, fixed;
-                    if (CK == 32) {
-                        // two workgroups share the CU's MFMA pipes: a tap step of one takes about twice its own MFMA
-                        // time (NB*4 MFMAs of 16 clocks); the partner's MFMAs cover this one's fill and epilogue
-                        per_tap = k2wg * 2.0 * NB * 4 * 16;
-                        fill = 6.0 * rows;
-                        fixed = 2000.0 + 4000.0;
-                    } else {
-                        per_tap = NW == 8 ? 1550.0 : (wgcu == 2 ? 1700.0 : 2500.0);
-                        if (pad) per_tap *= vc_halo_kpad / 1550.0;
-                        fill = 11.5 * rows;
-                        fixed = 2000.0 + 7000.0;
+                // masked form: half-filled tiles as well -- on tiny planes (layer4: 64 planes of 4 x 4) more, smaller
+                // workgroups fill the chip where full tiles leave half of it idle (VC_HALO_NO_SHRINK=1: full tiles only)
+                static const bool no_shrink = getenv("VC_HALO_NO_SHRINK") != nullptr;
+                for (int shrink = 1; shrink <= ((pad || no_shrink) ? 1 : 2); shrink *= 2) {
+                    int TT = BM / SEG / shrink;
+                    if (TT > NP) TT = NP;
+                    if (pad) {
+                        if (TT > T) TT = T;
+                        while (TT > 1 && T % TT != 0) --TT;  // a tile must not straddle two samples
                     }
-                    const double t_wg = fixed + cps * (fill + ntaps * per_tap);
-                    double cost = rounds * t_wg;
-                    if (splits > 1) cost += 15000.0 + 2.4e3 * ((double)NP * HW * Cn * 4.0 * (splits + 0.5)) / 4.0e6;
-                    if (cost < best) {
-                        best = cost;
-                        bp.NW = NW, bp.TT = TT, bp.SEG = SEG, bp.splits = splits, bp.CK = CK, bp.pad = pad, bp.NB = NB;
+                    if (TT < 1) continue;
+                    const int HR = pad ? (SEG / W + 2) * (W + 1) + 1 : SEG + 2 * W + 2;
+                    const int rows = (TT + 2) * HR;
+                    const int npieces = (rows + PR - 1) / PR;
+                    const int lds = halo_lds(NW, CK, npieces, NB);
+                    if (lds > 160 * 1024) continue;
+                    if (CK == 32 && 2 * lds > 160 * 1024) continue;  // the 32-channel forms exist for two workgroups per CU
+                    const int wgcu = (NW == 4 && 2 * lds <= 160 * 1024) ? 2 : 1;
+                    const long tiles = (long)((NP + TT - 1) / TT) * ((HW + SEG - 1) / SEG);
+                    for (int splits = 1; splits <= nchunks; splits *= 2) {
+                        const int cps = (nchunks + splits - 1) / splits;
+                        const long wgs = tiles * (Cn / 64) * splits;
+                        const long rounds = (wgs + 256L * wgcu - 1) / (256L * wgcu);
+                        double per_tap, fill, fixed;
+                        if (CK == 32) {
+                            // two workgroups share the CU's MFMA pipes: a tap step of one takes about twice its own MFMA
+                            // time (NB*4 MFMAs of 16 clocks); the partner's MFMAs cover this one's fill and epilogue
+                            per_tap = k2wg * 2.0 * NB * 4 * 16;
+                            fill = 6.0 * rows;
+                            fixed = 2000.0 + 4000.0;
+                        } else {
+                            per_tap = NW == 8 ? 1550.0 : (wgcu == 2 ? 1700.0 : 2500.0);
+                            if (pad) per_tap *= vc_halo_kpad / 1550.0;
+                            fill = 11.5 * rows;
+                            fixed = 2000.0 + 7000.0;
+                        }
+                        const double t_wg = fixed + cps * (fill + ntaps * per_tap);
+                        double cost = rounds * t_wg;
+                        if (splits > 1) cost += 15000.0 + 2.4e3 * ((double)NP * HW * Cn * 4.0 * (splits + 0.5)) / 4.0e6;
+                        if (cost < best) {
+                            best = cost;
+                            bp.NW = NW, bp.TT = TT, bp.SEG = SEG, bp.splits = splits, bp.CK = CK, bp.pad = pad, bp.NB = NB;
+                        }
                     }
                 }
             }
