@@ -213,6 +213,53 @@ def main_lstm():
     dist.destroy_process_group()
 
 
+def main_steps():
+    """Several training steps through the wrapper with the step RECORDED (vc3d/replay.py): the data-parallel backward
+    replays in segments that end where a gradient became final, and the wrapper launches its buckets between them.
+    One rank, RCCL, the injected doubling collective (a bucket launched before its last gradient was final misses that
+    gradient's doubling): the replayed run must end with the same parameters as the eager run, bit for bit, and both
+    with exactly what the doubling implies; the AVG collective likewise against the plain, unwrapped run."""
+    import vc3d.engine as eng_mod
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+
+    def run(wrap, inject, replay, steps=6):
+        eng_mod.REPLAY = replay
+        cfg, model, crit, opt = build(lr=0.02)
+        net = DataParallel3D(model, bucket_mb=4, tail_mb=0.25, grad_dtype="fp32") if wrap else model
+        net.train()
+        g = torch.Generator().manual_seed(11)
+        info = None
+        for i in range(steps):
+            x = torch.randn(8, 3, 8, 64, 64, generator=g).to(torch.bfloat16).cuda()
+            y = torch.randint(0, 11, (8,), generator=g).cuda()
+            _, score, _ = net(x)
+            loss = crit(score, y, None, None)
+            opt.zero_grad()
+            if inject and wrap:
+                net._ensure().collective = lambda seg: seg.mul_(2)
+            loss.backward()
+            opt.step()
+            t = model.backbone.engine._tape
+            if t is not None and t["bwd"] is not None:
+                info = (t["serial"], t["bwd"].n, len(t["bwd"].marks))
+        torch.cuda.synchronize()
+        eng = model.backbone.engine
+        return eng.flat_param.clone(), eng.flat_grad.clone(), info
+
+    plain_p, plain_g, plain_info = run(False, False, True)
+    avg_e_p, avg_e_g, _ = run(True, False, False)
+    avg_r_p, avg_r_g, avg_info = run(True, False, True)
+    inj_e_p, inj_e_g, _ = run(True, True, False)
+    inj_r_p, inj_r_g, inj_info = run(True, True, True)
+    eng_mod.REPLAY = True
+    print("DDP_STEPS avg_replay_vs_eager=%g avg_vs_plain=%g inject_replay_vs_eager=%g inject_vs_plain_grad=%g "
+          "plain=%s wrapped=%s injected=%s" % (
+              rel(avg_r_p, avg_e_p) + rel(avg_r_g, avg_e_g), rel(avg_r_p, plain_p), rel(inj_r_p, inj_e_p) + rel(inj_r_g, inj_e_g),
+              rel(inj_r_p, plain_p), plain_info, avg_info, inj_info), flush=True)
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     import faulthandler
     faulthandler.dump_traceback_later(100, exit=True)  # a stuck collective names itself instead of hanging the box
@@ -220,5 +267,7 @@ if __name__ == "__main__":
         main_shards()
     elif len(sys.argv) > 1 and sys.argv[1] == "lstm":
         main_lstm()
+    elif len(sys.argv) > 1 and sys.argv[1] == "steps":
+        main_steps()
     else:
         main_identity()

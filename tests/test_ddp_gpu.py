@@ -105,6 +105,29 @@ def test_recurrent_head_gradients_are_averaged_over_ranks():
     assert float(m.group(2)) <= 1e-5 and float(m.group(3)) <= 1e-5
 
 
+def test_data_parallel_backward_replays_in_segments():
+    """Six training steps through DataParallel3D with the step recorded (vc3d/replay.py): from the third step on the
+    backward is a command list replayed in segments -- one per point where a gradient became final -- with the wrapper's
+    bucket launches between them.  One rank, RCCL, deterministic mode: (a) AVG buckets: replayed == eager bit for bit,
+    and == the plain unwrapped run (an AVG over one rank is exact); (b) the injected doubling collective: replayed ==
+    eager bit for bit -- a bucket launched before its last gradient was final would miss that gradient's doubling --
+    and far from the plain run (the doubling is really applied).  The recorded backward must hold the marks."""
+    r = _torchrun([os.path.join(ROOT, "tests", "ddp_worker.py"), "steps"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    m = re.search(r"DDP_STEPS avg_replay_vs_eager=(\S+) avg_vs_plain=(\S+) inject_replay_vs_eager=(\S+) "
+                  r"inject_vs_plain_grad=(\S+) plain=\((\d+), (\d+), (\d+)\) wrapped=\((\d+), (\d+), (\d+)\) "
+                  r"injected=\((\d+), (\d+), (\d+)\)", r.stdout)
+    assert m, r.stdout[-2000:]
+    print(m.group(0))
+    assert float(m.group(1)) == 0.0 and float(m.group(3)) == 0.0
+    assert float(m.group(2)) <= 1e-7
+    assert float(m.group(4)) > 1e-3
+    plain, wrapped, injected = (tuple(int(m.group(i + j)) for j in range(3)) for i in (5, 8, 11))
+    assert plain[0] >= 3 and plain[2] == 0                        # replayed steps, no marks without the wrapper
+    assert wrapped[0] >= 3 and wrapped[2] >= 20 and wrapped[1] == plain[1]  # same commands, cut at the readiness points
+    assert injected[0] >= 3 and injected[2] == wrapped[2]
+
+
 def test_bench_under_torchrun_with_rccl_buckets():
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "8",
                    "--no-cpu-baseline"])

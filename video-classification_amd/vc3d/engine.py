@@ -276,7 +276,12 @@ class R3DEngine:
         return self.grad_views[id(p)].permute(0, 2, 3, 4, 1)
 
     def _ready(self, *params):
+        """the gradients of `params` are final in stream order from here on (the data-parallel wrapper launches a
+        bucket's all-reduce when its last gradient is).  While a backward is being recorded the point is marked in the
+        command list as well: its replay stops there and makes the same calls (CommandList.replay_segments)."""
         if self.grad_ready_cb is not None:
+            if capi.RECORDER is not None:
+                capi.RECORDER.mark(params)
             for p in params:
                 self.grad_ready_cb(p)
 
@@ -505,16 +510,24 @@ class R3DEngine:
             raise Vc3dError("backward of a recorded step whose activations have been overwritten by a later step")
         tape["live"] = None
         df = dfeat.contiguous()
-        eager = (tape is not self._tape or self.grad_ready_cb is not None or self.backward_done_cb is not None or
-                 self.trace is not None or (ops.TIMER is not None and ops.TIMER.select is None) or
+        eager = (tape is not self._tape or self.trace is not None or (ops.TIMER is not None and ops.TIMER.select is None) or
                  capi.cur_stream() != tape["key"][3] or self.flat_grad.data_ptr() != tape["key"][4])
         if eager:
-            # (data-parallel buckets are launched from Python between the kernels: that backward stays eager, the
-            # forward keeps its recording)
             return self._backward(tape["saved"], df)
-        if tape["bwd"] is not None:
-            tape["bwd"].patch("dfeat", df.data_ptr())
-            tape["bwd"].replay()
+        bwd = tape["bwd"]
+        if bwd is not None and bool(bwd.marks) != (self.grad_ready_cb is not None):
+            bwd = tape["bwd"] = None  # recorded with / without a data-parallel wrapper, now the other way round: again
+        if bwd is not None:
+            bwd.patch("dfeat", df.data_ptr())
+            self._main = torch.cuda.current_stream()
+            if bwd.marks:
+                # data parallel: the wrapper's bucket launches come from Python between the kernels -- the list is
+                # replayed in segments that end where a gradient became final while it was recorded
+                bwd.replay_segments(lambda params: self._ready(*params))
+            else:
+                bwd.replay()
+            if self.backward_done_cb is not None:
+                self.backward_done_cb()
             return None
         rec = Recorder()
         ops.TAPE, capi.RECORDER = tape["tensors"], rec

@@ -25,6 +25,7 @@ class Recorder:
         self.n_events = 0
         self.tag = None     # set by ops around a conv launch: the KernelTimer key of the next command
         self.failed = None
+        self.marks = []     # (number of commands recorded before it, payload): points where Python runs between commands
 
     # ---- calls (capi._Lib)
     def add(self, name, fn, argtypes, args, rc):
@@ -72,6 +73,11 @@ class Recorder:
     def stream_wait(self, stream_handle, ev):
         self.cmds.append((CMD_STREAM_WAIT, 0, [ev, int(stream_handle)], [], "stream_wait", None))
 
+    def mark(self, payload):
+        """a point between two commands where the replaying side has work of its own (the data-parallel wrapper's
+        bucket launches): CommandList.replay_segments stops there and hands `payload` to its callback."""
+        self.marks.append((len(self.cmds), payload))
+
     def freeze(self, patch_values=()):
         """-> CommandList.  patch_values: {name: pointer value}; every integer argument equal to one of them becomes a
         patch point of that name."""
@@ -103,6 +109,7 @@ class CommandList:
             if tag is not None:
                 self.tags.setdefault(tag, i)
         self.keep = rec.keep
+        self.marks = list(rec.marks)
         self.n_events = rec.n_events
         self.events = (C.c_void_p * max(self.n_events, 1))()
         if self.n_events:
@@ -120,10 +127,25 @@ class CommandList:
         for i, j in self.patches[name]:
             self.array[i].iarg[j] = value
 
-    def replay(self, time_cmd=-1, time_start=None, time_stop=None):
-        rc = capi.lib.vc_replay(self.array, self.n, self.events, self.n_events, time_cmd, time_start, time_stop,
-                                C.byref(self._failed_at))
+    def replay(self, time_cmd=-1, time_start=None, time_stop=None, first=0, end=None):
+        """commands [first, end) (default: all of them)"""
+        end = self.n if end is None else end
+        if end <= first:
+            return
+        cmds = self.array if first == 0 else C.byref(self.array[first])
+        rc = capi.lib.vc_replay(cmds, end - first, self.events, self.n_events, time_cmd - first if time_cmd >= first else -1,
+                                time_start, time_stop, C.byref(self._failed_at))
         if rc != 0:
-            i = self._failed_at.value
+            i = self._failed_at.value + first
             raise Vc3dError("replay failed at command %d (%s): %s" % (i, self.names[i] if 0 <= i < self.n else "?",
                                                                       capi.lib.vc_last_error().decode()))
+
+    def replay_segments(self, on_mark):
+        """the whole list, stopping at every recorded mark to call on_mark(payload) -- everything recorded before the
+        mark has been enqueued by then, nothing after it, exactly as when the step ran from Python."""
+        pos = 0
+        for at, payload in self.marks:
+            self.replay(first=pos, end=at)
+            pos = at
+            on_mark(payload)
+        self.replay(first=pos, end=self.n)
