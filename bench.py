@@ -166,17 +166,24 @@ def family_rooflines(table):
     if not fam:
         return None
     tot = sum(f[1] for f in fam.values())
-    name, (n, ms, fl, by) = max(fam.items(), key=lambda kv: kv[1][1])
-    out = {"kernel": name, "launches_per_step": n, "ms_per_step": round(ms, 4), "share_of_conv_time": round(ms / tot, 4)}
-    if by > 0:
-        gbs = by / (ms * 1e-3) / 1e9
-        out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(gbs / PEAK_HBM_GBS, 4)})
-    else:
-        ach = fl / (ms * 1e-3) / 1e12
-        out.update({"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4)})
-    return out
+
+    def entry(name, n, ms, fl, by):
+        out = {"kernel": name, "launches_per_step": n, "ms_per_step": round(ms, 4), "share_of_conv_time": round(ms / tot, 4)}
+        if by > 0:
+            gbs = by / (ms * 1e-3) / 1e9
+            out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        else:
+            ach = fl / (ms * 1e-3) / 1e12
+            out.update({"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_BF16_TFLOPS, 4)})
+        return out
+
+    ranked = sorted(fam.items(), key=lambda kv: -kv[1][1])
+    top = entry(ranked[0][0], *ranked[0][1])
+    # every family, largest first: the headline `roofline` is the best of the big kernels, these are all of them
+    top["families"] = [entry(name, *f) for name, f in ranked]
+    return top
 
 
 def bench_multi_view(args, cfg, net, criterion, dev, rank, world, ddp):
