@@ -260,6 +260,48 @@ def main_steps():
     dist.destroy_process_group()
 
 
+def main_steps2():
+    """Two ranks (gloo, both on cuda:0, buckets staged through the host), five training steps each on its own shard,
+    with the step recorded and with it eager: the ranks must end with identical parameters in both runs (the buckets
+    of the segmented replay line up across ranks), and the replayed run must equal the eager one bit for bit."""
+    import vc3d.engine as eng_mod
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def run(replay, steps=5):
+        eng_mod.REPLAY = replay
+        cfg, model, crit, opt = build(lr=0.02)
+        net = DataParallel3D(model, bucket_mb=4, tail_mb=0.25, grad_dtype="fp32")
+        net.train()
+        g = torch.Generator().manual_seed(21 + rank)
+        info = None
+        for i in range(steps):
+            x = torch.randn(8, 3, 8, 64, 64, generator=g).to(torch.bfloat16).cuda()
+            y = torch.randint(0, 11, (8,), generator=g).cuda()
+            loss = crit(net(x)[1], y, None, None)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            t = model.backbone.engine._tape
+            if t is not None and t["bwd"] is not None:
+                info = (t["serial"], len(t["bwd"].marks))
+        torch.cuda.synchronize()
+        p = model.backbone.engine.flat_param.cpu()
+        both = [torch.zeros_like(p) for _ in range(world)]
+        dist.all_gather(both, p)
+        return p, all(torch.equal(both[0], t) for t in both), info
+
+    pe, same_e, _ = run(False)
+    pr, same_r, info = run(True)
+    eng_mod.REPLAY = True
+    if rank == 0:
+        print("DDP_STEPS2 ranks_agree_eager=%d ranks_agree_replay=%d replay_vs_eager=%g recorded=%s" % (
+            int(same_e), int(same_r), rel(pr, pe), info), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     import faulthandler
     faulthandler.dump_traceback_later(100, exit=True)  # a stuck collective names itself instead of hanging the box
@@ -269,5 +311,7 @@ if __name__ == "__main__":
         main_lstm()
     elif len(sys.argv) > 1 and sys.argv[1] == "steps":
         main_steps()
+    elif len(sys.argv) > 1 and sys.argv[1] == "steps2":
+        main_steps2()
     else:
         main_identity()

@@ -128,6 +128,24 @@ def test_data_parallel_backward_replays_in_segments():
     assert injected[0] >= 3 and injected[2] == wrapped[2]
 
 
+def test_two_ranks_train_several_recorded_steps_in_lockstep():
+    """Two ranks (gloo, sharing the GPU), five training steps each on its own data through DataParallel3D with the step
+    recorded: the segmented replay of the backward launches the same buckets in the same order on both ranks (no
+    deadlock, no mismatch), the ranks end with identical parameters, and these equal the eager run's bit for bit
+    (deterministic mode)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_DETERMINISTIC="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_worker.py"), "steps2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    m = re.search(r"DDP_STEPS2 ranks_agree_eager=(\d) ranks_agree_replay=(\d) replay_vs_eager=(\S+) recorded=\((\d+), (\d+)\)",
+                  r.stdout)
+    assert m, r.stdout[-2000:]
+    print(m.group(0))
+    assert m.group(1) == "1" and m.group(2) == "1" and float(m.group(3)) == 0.0
+    assert int(m.group(4)) >= 2 and int(m.group(5)) >= 20
+
+
 def test_bench_under_torchrun_with_rccl_buckets():
     r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "8",
                    "--no-cpu-baseline"])
