@@ -220,8 +220,11 @@ class DataParallel3D(torch.nn.Module):
 
     def extra_params(self):
         eng = self.module.backbone.engine
-        flat = {id(p) for p, _, _ in eng.grad_ranges}
-        return [p for p in self.module.parameters() if p.requires_grad and id(p) not in flat]
+        cache = getattr(self, "_extras_cache", None)  # (per flat-buffer layout: this runs at the end of every backward)
+        if cache is None or cache[0] is not eng.grad_ranges:
+            flat = {id(p) for p, _, _ in eng.grad_ranges}
+            cache = self._extras_cache = (eng.grad_ranges, [p for p in self.module.parameters() if id(p) not in flat])
+        return [p for p in cache[1] if p.requires_grad]
 
     def _reduce_extras(self):
         self._extras_queued = False
