@@ -242,7 +242,7 @@ def main_steps():
             opt.step()
             t = model.backbone.engine._tape
             if t is not None and t["bwd"] is not None:
-                info = (t["serial"], t["bwd"].n, len(t["bwd"].marks))
+                info = (t["serial"], t["bwd"].n, len(t["bwd"].marks), sum(1 for m in t["bwd"].marks if m[2]))
         torch.cuda.synchronize()
         eng = model.backbone.engine
         return eng.flat_param.clone(), eng.flat_grad.clone(), info

@@ -115,17 +115,18 @@ def test_data_parallel_backward_replays_in_segments():
     r = _torchrun([os.path.join(ROOT, "tests", "ddp_worker.py"), "steps"])
     assert r.returncode == 0, r.stderr[-3000:]
     m = re.search(r"DDP_STEPS avg_replay_vs_eager=(\S+) avg_vs_plain=(\S+) inject_replay_vs_eager=(\S+) "
-                  r"inject_vs_plain_grad=(\S+) plain=\((\d+), (\d+), (\d+)\) wrapped=\((\d+), (\d+), (\d+)\) "
-                  r"injected=\((\d+), (\d+), (\d+)\)", r.stdout)
+                  r"inject_vs_plain_grad=(\S+) plain=\((\d+), (\d+), (\d+), (\d+)\) wrapped=\((\d+), (\d+), (\d+), (\d+)\) "
+                  r"injected=\((\d+), (\d+), (\d+), (\d+)\)", r.stdout)
     assert m, r.stdout[-2000:]
     print(m.group(0))
     assert float(m.group(1)) == 0.0 and float(m.group(3)) == 0.0
     assert float(m.group(2)) <= 1e-7
     assert float(m.group(4)) > 1e-3
-    plain, wrapped, injected = (tuple(int(m.group(i + j)) for j in range(3)) for i in (5, 8, 11))
+    plain, wrapped, injected = (tuple(int(m.group(i + j)) for j in range(4)) for i in (5, 9, 13))
     assert plain[0] >= 3 and plain[2] == 0                        # replayed steps, no marks without the wrapper
-    assert wrapped[0] >= 3 and wrapped[2] >= 20 and wrapped[1] == plain[1]  # same commands, cut at the readiness points
-    assert injected[0] >= 3 and injected[2] == wrapped[2]
+    assert wrapped[0] >= 3 and wrapped[2] >= 20 and wrapped[1] == plain[1]  # same commands, marked at the readiness points
+    assert 3 <= wrapped[3] <= 12 < wrapped[2]                     # ... and cut only where a bucket was launched (11 buckets,
+    assert injected[0] >= 3 and injected[2:] == wrapped[2:]      # the head's and the last one outside the recorded list)
 
 
 def test_two_ranks_train_several_recorded_steps_in_lockstep():

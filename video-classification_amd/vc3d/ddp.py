@@ -82,14 +82,17 @@ class GradBucketReducer:
         self.launched = [False] * len(self.buckets)
 
     def on_ready(self, key):
+        """-> True when this gradient completed a bucket and its all-reduce was launched"""
         if not self.enabled:
-            return
+            return False
         b = self.key2bucket.get(key)
         if b is None:
-            return
+            return False
         self.pending[b] -= 1
         if self.pending[b] == 0:
             self._launch(b)
+            return True
+        return False
 
     def _reduce(self, seg, start, end):
         """average `seg` over the group, on the current (communication) stream / thread."""
@@ -201,7 +204,7 @@ class DataParallel3D(torch.nn.Module):
     def _on_ready(self, p):
         r = self._ensure()
         r.enabled = self._sync
-        r.on_ready(id(p))
+        return r.on_ready(id(p))
 
     def _on_done(self):
         r = self._ensure()

@@ -280,10 +280,12 @@ class R3DEngine:
         bucket's all-reduce when its last gradient is).  While a backward is being recorded the point is marked in the
         command list as well: its replay stops there and makes the same calls (CommandList.replay_segments)."""
         if self.grad_ready_cb is not None:
-            if capi.RECORDER is not None:
-                capi.RECORDER.mark(params)
+            cut = False
             for p in params:
-                self.grad_ready_cb(p)
+                r = self.grad_ready_cb(p)  # True: it enqueued work (a bucket's all-reduce); None: unknown, assume so
+                cut = cut or r is None or bool(r)
+            if capi.RECORDER is not None:
+                capi.RECORDER.mark(params, cut)
 
     def _wgrad(self, d, h, dy, conv):
         """weight gradient of one conv.  Nothing downstream in backward consumes it, so it is issued on a side

@@ -73,10 +73,12 @@ class Recorder:
     def stream_wait(self, stream_handle, ev):
         self.cmds.append((CMD_STREAM_WAIT, 0, [ev, int(stream_handle)], [], "stream_wait", None))
 
-    def mark(self, payload):
+    def mark(self, payload, cut=True):
         """a point between two commands where the replaying side has work of its own (the data-parallel wrapper's
-        bucket launches): CommandList.replay_segments stops there and hands `payload` to its callback."""
-        self.marks.append((len(self.cmds), payload))
+        bucket launches): CommandList.replay_segments hands `payload` to its callback there.  cut=False: the callback
+        enqueued nothing when the step was recorded (a gradient became final without completing a bucket) -- the
+        replay need not stop for it and makes the call at the next mark that does cut, in order."""
+        self.marks.append((len(self.cmds), payload, bool(cut)))
 
     def freeze(self, patch_values=()):
         """-> CommandList.  patch_values: {name: pointer value}; every integer argument equal to one of them becomes a
@@ -143,9 +145,16 @@ class CommandList:
     def replay_segments(self, on_mark):
         """the whole list, stopping at every recorded mark to call on_mark(payload) -- everything recorded before the
         mark has been enqueued by then, nothing after it, exactly as when the step ran from Python."""
-        pos = 0
-        for at, payload in self.marks:
+        pos, waiting = 0, []
+        for at, payload, cut in self.marks:
+            waiting.append(payload)
+            if not cut:
+                continue
             self.replay(first=pos, end=at)
             pos = at
-            on_mark(payload)
+            for w in waiting:
+                on_mark(w)
+            waiting = []
         self.replay(first=pos, end=self.n)
+        for w in waiting:
+            on_mark(w)
