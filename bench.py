@@ -298,6 +298,7 @@ def main():
     criterion = Loss(cfg).to(dev)
     optimizer = create_optimizer(cfg, model)
     net = DataParallel3D(model) if ddp else model
+    arm = getattr(optimizer, "arm_backward", lambda: False)
 
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, args.clip_len, args.crop, args.crop, generator=g).to(torch.bfloat16).to(dev)
@@ -318,6 +319,7 @@ def main():
             _, score, _ = net(x)
             loss = criterion(score, y, None, None)
             optimizer.zero_grad()
+            arm()  # (this backward makes the step's complete gradients: the fused optimizer may step inside it)
             loss.backward()
             optimizer.step()
 

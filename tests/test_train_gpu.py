@@ -127,6 +127,62 @@ def test_flat_sgd_matches_torch_sgd(nesterov):
     assert torch.isfinite(loss)
 
 
+@pytest.mark.parametrize("name", ["sgd", "adam"])
+def test_optimizer_stepping_inside_the_backward_changes_nothing(name, det_mode):
+    """optimizer.arm_backward(): the fused optimizers apply their step to the finished prefix of the flat buffers in
+    slices while the backward still runs (side stream, behind the weight gradient that completed the prefix), step()
+    does the rest.  Deterministic sums, so two runs are comparable bit for bit: after every one of five steps (the first
+    eager + recorded, the next replayed in segments, the fourth NOT armed -- the backward is recorded again without
+    marks -- the fifth armed again) parameters, momentum / moments and the bf16 operands equal those of a model stepped
+    the plain way."""
+    from models.model import create_model
+    from utils.utils import create_optimizer
+    torch.manual_seed(0)
+    cfg = make_config(18, 7, OPTIMIZER=name, LR=0.05 if name == "sgd" else 1e-3, MOMENTUM=0.9, WD=1e-3, NESTEROV=False)
+    x = torch.randn(4, 3, 4, 32, 32).cuda()
+    y = torch.randint(0, 7, (4,)).cuda()
+    runs = []
+    for armed in (False, True):
+        torch.manual_seed(1)
+        model = create_model(cfg, True).cuda().train()
+        opt = create_optimizer(cfg, model)
+        slices = []
+        apply = opt._apply
+        opt._apply = lambda eng, a, b, apply=apply, slices=slices: (slices.append((a, b, torch.cuda.current_stream().cuda_stream)),
+                                                                    apply(eng, a, b))
+        snaps = []
+        for step in range(5):
+            _, score, _ = model(x)
+            loss = F.cross_entropy(score, y)
+            opt.zero_grad()
+            n0 = len(slices)
+            if armed and step != 3 and step != 0:  # (step 0 sets the flat buffers up: nothing to arm yet)
+                assert opt.arm_backward()
+            loss.backward()
+            in_backward = len(slices) - n0
+            opt.step()
+            torch.cuda.synchronize()
+            eng = model.backbone.engine
+            if armed and step in (1, 2, 4):
+                assert in_backward >= 3, in_backward  # layer4's convs are 3.5 - 7 M elements each
+                mine = slices[n0:]
+                assert mine[0][0] == 0 and all(a[1] == b[0] for a, b in zip(mine, mine[1:])) and mine[-1][1] == eng.flat_param.numel()
+                assert all(sl[2] == eng._side.cuda_stream for sl in mine[:-1]) and mine[-1][2] != eng._side.cuda_stream
+            else:
+                assert in_backward == 0 and len(slices) - n0 == 1
+            state = [opt.mom] if name == "sgd" else [opt.exp_avg, opt.exp_avg_sq]
+            snaps.append([t.clone() for t in [eng.flat_param, eng.flat_shadow, eng.flat_wd] + state] + [float(loss)])
+        runs.append(snaps)
+    for step, (a, b) in enumerate(zip(*runs)):
+        assert a[-1] == b[-1], step
+        for u, v in zip(a[:-1], b[:-1]):
+            assert torch.equal(u, v), step
+    with pytest.raises(Exception, match="again before step"):
+        opt.arm_backward()
+        opt.arm_backward()
+    opt.step()  # (clears the armed state)
+
+
 def test_flat_adam_matches_torch_adam():
     """create_optimizer's 'adam' (the reference's default optimizer, config.py:43, utils.py:30-33) on the GPU is the
     fused flat step (vc_adam_step): against torch.optim.Adam(lr) on the same gradients, three steps (both moments and

@@ -75,6 +75,8 @@ def train(config, train_loader, model, criterion, optimizer, epoch):
             log_prob, advantages = rollout(vedio, model, action, value)
             loss = criterion(score, target, log_prob, advantages)
             optimizer.zero_grad()
+            if hasattr(optimizer, "arm_backward"):
+                optimizer.arm_backward()  # one backward per step, nothing edits the gradients: the step may start inside it
             loss.backward()
             optimizer.step()
             loss_acc += loss.detach()

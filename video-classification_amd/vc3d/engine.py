@@ -111,6 +111,9 @@ class R3DEngine:
         self._side = None          # side stream of the weight-gradient launches (see _wgrad)
         self._main = None          # the stream backward was issued on (what a bucket all-reduce must also wait for)
         self.backward_done_cb = None
+        # set by a fused optimizer for ONE backward (optim.arm_backward): hook(params, side_stream or None) -> True when
+        # it launched a slice of its step; not used together with grad_ready_cb
+        self.opt_hook = None
         self._stem_scratch = None
         self._tickets = None       # zero int32 words of the fused BatchNorm finalize (see _ticket)
         self._ticket_ix = None
@@ -275,17 +278,30 @@ class R3DEngine:
         """physical [Co][kt][kh][kw][Ci] contiguous view of a conv weight gradient."""
         return self.grad_views[id(p)].permute(0, 2, 3, 4, 1)
 
-    def _ready(self, *params):
+    def _ready(self, *params, side=None):
         """the gradients of `params` are final in stream order from here on (the data-parallel wrapper launches a
         bucket's all-reduce when its last gradient is).  While a backward is being recorded the point is marked in the
         command list as well: its replay stops there and makes the same calls (CommandList.replay_segments)."""
-        if self.grad_ready_cb is not None:
+        if self.grad_ready_cb is None and self.opt_hook is None:
+            return
+        # what the callbacks enqueue is theirs to enqueue again when the step is replayed: it is not recorded
+        rec, capi.RECORDER = capi.RECORDER, None
+        try:
             cut = False
-            for p in params:
-                r = self.grad_ready_cb(p)  # True: it enqueued work (a bucket's all-reduce); None: unknown, assume so
-                cut = cut or r is None or bool(r)
-            if capi.RECORDER is not None:
-                capi.RECORDER.mark(params, cut)
+            if self.grad_ready_cb is not None:
+                for p in params:
+                    r = self.grad_ready_cb(p)  # True: it enqueued work (a bucket's all-reduce); None: unknown, assume so
+                    cut = cut or r is None or bool(r)
+            else:
+                # side = "side": this point is in the side stream's order (a weight gradient was just issued there), and
+                # everything made final so far, on either stream, precedes it there; "main": the step runs on one
+                # stream; None: a main-stream point while weight gradients are in flight on the side stream
+                stream = self._side if side == "side" else torch.cuda.current_stream() if side == "main" else None
+                cut = bool(self.opt_hook(params, stream))
+        finally:
+            capi.RECORDER = rec
+        if rec is not None:
+            rec.mark((params, side), cut)
 
     def _wgrad(self, d, h, dy, conv):
         """weight gradient of one conv.  Nothing downstream in backward consumes it, so it is issued on a side
@@ -294,7 +310,7 @@ class R3DEngine:
         weight-gradient kernels instead of waiting behind them.  Joined at the end of backward."""
         if not SIDE_WGRAD or self.trace is not None:
             ops.conv3d_wgrad(d, h, dy, self._gphys(conv.weight))
-            self._ready(conv.weight)
+            self._ready(conv.weight, side="main")
             return
         if self._side is None or self._side.device != dy.device:
             self._side = torch.cuda.Stream(device=dy.device)
@@ -307,7 +323,7 @@ class R3DEngine:
             if rec is not None:
                 rec.stream_wait(capi.cur_stream(), rev)
             ops.conv3d_wgrad(d, h, dy, self._gphys(conv.weight))
-            self._ready(conv.weight)  # a bucket all-reduce must wait for THIS stream: the event is recorded here
+            self._ready(conv.weight, side="side")  # a bucket all-reduce must wait for THIS stream: the event is recorded here
         dy.record_stream(self._side)  # dy is dropped right after the dgrad on the main stream
         h.record_stream(self._side)
 
@@ -517,15 +533,17 @@ class R3DEngine:
         if eager:
             return self._backward(tape["saved"], df)
         bwd = tape["bwd"]
-        if bwd is not None and bool(bwd.marks) != (self.grad_ready_cb is not None):
-            bwd = tape["bwd"] = None  # recorded with / without a data-parallel wrapper, now the other way round: again
+        if bwd is not None and bool(bwd.marks) != (self.grad_ready_cb is not None or self.opt_hook is not None):
+            # recorded with / without a data-parallel wrapper (or an optimizer stepping inside the backward), now the
+            # other way round: again
+            bwd = tape["bwd"] = None
         if bwd is not None:
             bwd.patch("dfeat", df.data_ptr())
             self._main = torch.cuda.current_stream()
             if bwd.marks:
                 # data parallel: the wrapper's bucket launches come from Python between the kernels -- the list is
                 # replayed in segments that end where a gradient became final while it was recorded
-                bwd.replay_segments(lambda params: self._ready(*params))
+                bwd.replay_segments(lambda m: self._ready(*m[0], side=m[1]))
             else:
                 bwd.replay()
             if self.backward_done_cb is not None:
