@@ -34,7 +34,7 @@ step "other configs" && {
   VC_DDP_FORCE_COMM=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline 2>/dev/null
 } > $O/bench_other_configs.jsonl
 step "host enqueue" && { timeout -k 10 200 python3 scripts/cpu_enqueue.py 18 && timeout -k 10 200 python3 scripts/cpu_enqueue.py 50; } > $O/cpu_enqueue.txt 2>&1
-step "timeline" && timeout -k 10 300 rocprofv3 --kernel-trace -d $O/tl -o p -- python3 bench.py --steps 10 --warmup 10 --no-cpu-baseline > $O/tl.log 2>&1 && python3 scripts/step_timeline.py $O/tl/p_results.db > $O/step_timeline.txt
+step "timeline" && timeout -k 10 300 rocprofv3 --kernel-trace -d $O/tl -o p -- python3 bench.py --steps 10 --warmup 10 --no-cpu-baseline > $O/tl.log 2>&1 && python3 scripts/step_timeline.py $O/tl/p_results.db --marker pack_dgrad_batched_kernel > $O/step_timeline.txt
 rm -rf $O/tl
 rm -rf $O/trace18 $O/trace50 gpurun_out/pmc_$TAG/*/p_results.db gpurun_out/pmc_${TAG}_r50/*/p_results.db 2>/dev/null
 ls $O

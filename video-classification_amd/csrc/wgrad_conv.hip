@@ -12,6 +12,8 @@
 // Work split: blockIdx.x = group of NB 64-wide column blocks (each block = one tap x 64 ci),
 // blockIdx.y = BCO-wide co block, blockIdx.z = slice of m (split-K).  Partial sums are added
 // to the fp32 gradient with float atomics (the gradient buffer is zeroed by the caller).
+// Global -> registers -> LDS, one LDS buffer, STAGES register sets: the next STAGES - 1 chunks' loads are in flight
+// while a chunk is multiplied.
 #include <stdlib.h>
 
 #include "common.h"
@@ -30,7 +32,7 @@ struct WgCfg {
     static_assert((BCO / 64) * NB == 4, "4 waves per workgroup");
 };
 
-template <int BCO, int NB, int MODE>
+template <int BCO, int NB, int MODE, int STAGES>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
     using Cfg = WgCfg<BCO, NB>;
     typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
@@ -103,10 +105,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
             }
     }
 
-    bf16x8 yr[Cfg::NY];
-    bf16x8 xr[NB][2];
+    // STAGES register sets of one chunk each: the loads of the next STAGES - 1 chunks are in flight while one is
+    // multiplied (a workgroup with ONE chunk in flight waits out most of every HBM round trip: 24-40 KB per ~2 us)
+    bf16x8 yrs[STAGES][Cfg::NY];
+    bf16x8 xrs[STAGES][NB][2];
 
-    auto load_chunk = [&](int c) {
+    auto load_chunk = [&](int c, bf16x8 (&yr)[Cfg::NY], bf16x8 (&xr)[NB][2]) {
         const int m = mb + c * 64 + lrow;
         const bool rowok = m < mend;
         int base = 0, s_t = 0, s_h = 0, s_w = 0;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
             }
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](const bf16x8 (&yr)[Cfg::NY], const bf16x8 (&xr)[NB][2]) {
 #pragma unroll
         for (int h = 0; h < Cfg::NY; ++h) *(bf16x8*)(sY + lrow * Cfg::RSY + (lsub + 4 * h) * 16) = yr[h];
 #pragma unroll
@@ -162,8 +166,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
     };
 
     // wave roles
-    const int wco = (BCO == 128) ? (wave & 1) : 0;
-    const int wb = (BCO == 128) ? (wave >> 1) : wave;
+    const int wco = wave % (BCO / 64);
+    const int wb = wave / (BCO / 64);
     const int l15 = lane & 15;
     const int lg = lane >> 4;
     const int q = l15 >> 2, pp = l15 & 3;
@@ -177,15 +181,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (nchunks > 0) {
-        load_chunk(0);
-        store_chunk();
-    }
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s)
+        if (s < nchunks) load_chunk(s, yrs[s], xrs[s]);
 
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = (c + 1 < nchunks);
-        if (more) load_chunk(c + 1);
+    for (int c0 = 0; c0 < nchunks; c0 += STAGES) {
+#pragma unroll
+      for (int s = 0; s < STAGES; ++s) {
+        const int c = c0 + s;
+        if (c >= nchunks) break;  // (uniform)
+        store_chunk(yrs[s], xrs[s]);
+        __syncthreads();
+        if (c + STAGES < nchunks) load_chunk(c + STAGES, yrs[s], xrs[s]);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
@@ -210,10 +217,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
-        if (more) {
-            store_chunk();
-            __syncthreads();
-        }
+      }
     }
 
     // ---- epilogue: acc[a][b][j] = dW[co0 + wco*64 + a*16 + lg*4 + j][col(wb) + b*16 + l15]
@@ -248,13 +252,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const VcWgradParams p) {
         }
 }
 
-template <int BCO, int NB, int MODE>
+template <int BCO, int NB, int MODE, int STAGES>
 int launch_wgrad(const VcWgradParams& p, int splits, hipStream_t stream) {
     using Cfg = WgCfg<BCO, NB>;
     const int nblk = (MODE == 0) ? p.ntaps * (p.Cs / 64) : p.Kw / 64;
     dim3 grid((nblk + NB - 1) / NB, p.Co / BCO, splits);
     (void)hipGetLastError();  // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((wgrad_kernel<BCO, NB, MODE>), grid, dim3(256), Cfg::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((wgrad_kernel<BCO, NB, MODE, STAGES>), grid, dim3(256), Cfg::LDS_BYTES, stream, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         vc_set_error("wgrad launch failed: %s", hipGetErrorString(e));
@@ -265,10 +269,17 @@ int launch_wgrad(const VcWgradParams& p, int splits, hipStream_t stream) {
 
 }  // namespace
 
+// one 64-wide column block (a pointwise conv from 64 channels) onto a multiple of 256 output channels: the 256 x 64 tile
+static bool wgrad_one_block(int Co, int nblk) {
+    static const bool off = getenv("VC_WGRAD_NO_256") != nullptr;
+    return nblk == 1 && Co % 256 == 0 && !off;
+}
+
 int vc_wgrad_splits(int M, int Co, int nblk, int* rows_per_split) {
     const bool wide = (Co % 128 == 0);
-    const int nb = wide ? 2 : 4;
-    const int bco = wide ? 128 : 64;
+    const bool one = wgrad_one_block(Co, nblk);
+    const int nb = one ? 1 : wide ? 2 : 4;
+    const int bco = one ? 256 : wide ? 128 : 64;
     const long tiles = (long)((nblk + nb - 1) / nb) * (Co / bco);
     // aim for ~192 workgroups, at least 4 chunks (256 rows) per split.  Every split costs a slab of the whole gradient
     // (written, then read by the reduce): in isolation 512 against 1024 measured 15-25 % faster on the 1x1x1 and the
@@ -303,7 +314,21 @@ int vc_launch_wgrad(const VcWgradParams& p_in, int mode, hipStream_t stream) {
     p.splits = splits;
     static const bool no_xcd_map = getenv("VC_NO_XCD_MAP") != nullptr || getenv("VC_WGRAD_NO_XCD_MAP") != nullptr;
     p.xcd_map = no_xcd_map ? 0 : 1;
-    if (mode == 1) return launch_wgrad<64, 4, 1>(p, splits, stream);
-    if (wide) return launch_wgrad<128, 2, 0>(p, splits, stream);
-    return launch_wgrad<64, 4, 0>(p, splits, stream);
+    static const int stages = getenv("VC_WGRAD_STAGES") ? atoi(getenv("VC_WGRAD_STAGES")) : 3;
+    if (mode == 1) return launch_wgrad<64, 4, 1, 1>(p, splits, stream);
+    if (mode == 0 && wgrad_one_block(p.Co, nblk)) {
+        // one 64-wide column block (a pointwise conv from 64 channels): four waves side by side along co, none idle,
+        // and x read once per 256 co instead of once per 128
+        if (stages <= 1) return launch_wgrad<256, 1, 0, 1>(p, splits, stream);
+        if (stages == 2) return launch_wgrad<256, 1, 0, 2>(p, splits, stream);
+        return launch_wgrad<256, 1, 0, 3>(p, splits, stream);
+    }
+    if (wide) {
+        if (stages <= 1) return launch_wgrad<128, 2, 0, 1>(p, splits, stream);
+        if (stages == 2) return launch_wgrad<128, 2, 0, 2>(p, splits, stream);
+        return launch_wgrad<128, 2, 0, 3>(p, splits, stream);
+    }
+    if (stages <= 1) return launch_wgrad<64, 4, 0, 1>(p, splits, stream);
+    if (stages == 2) return launch_wgrad<64, 4, 0, 2>(p, splits, stream);
+    return launch_wgrad<64, 4, 0, 3>(p, splits, stream);
 }
