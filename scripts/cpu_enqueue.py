@@ -23,7 +23,7 @@ if os.environ.get("VC_DDP_FORCE_COMM") == "1":  # one-rank RCCL rehearsal of the
 x = torch.randn(64, 3, 16, 112, 112).to(torch.bfloat16).cuda(); y = torch.randint(0, cfg.MODEL.CLFDIM, (64,)).cuda()
 model.train()
 def step():
-    _, s, _ = model(x); loss = crit(s, y, None, None); opt.zero_grad(); loss.backward(); opt.step()
+    _, s, _ = model(x); loss = crit(s, y, None, None); opt.zero_grad(); opt.arm_backward(); loss.backward(); opt.step()
 for _ in range(5): step()
 torch.cuda.synchronize()
 ts = []

@@ -22,7 +22,7 @@ if os.environ.get("VC_DDP_FORCE_COMM") == "1":
 x = torch.randn(32, 3, 16, 112, 112).to(torch.bfloat16).cuda(); y = torch.randint(0, 101, (32,)).cuda()
 model.train()
 def step():
-    _, s, _ = model(x); loss = crit(s, y, None, None); opt.zero_grad(); loss.backward(); opt.step(); return loss
+    _, s, _ = model(x); loss = crit(s, y, None, None); opt.zero_grad(); opt.arm_backward(); loss.backward(); opt.step(); return loss
 for _ in range(10): step()
 torch.cuda.synchronize()
 def snap(tag, t0, n):
