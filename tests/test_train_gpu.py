@@ -132,9 +132,10 @@ def test_optimizer_stepping_inside_the_backward_changes_nothing(name, det_mode):
     """optimizer.arm_backward(): the fused optimizers apply their step to the finished prefix of the flat buffers in
     slices while the backward still runs (side stream, behind the weight gradient that completed the prefix), step()
     does the rest.  Deterministic sums, so two runs are comparable bit for bit: after every one of five steps (the first
-    eager + recorded, the next replayed in segments, the fourth NOT armed -- the backward is recorded again without
-    marks -- the fifth armed again) parameters, momentum / moments and the bf16 operands equal those of a model stepped
-    the plain way."""
+    sets the flat buffers up, the second is armed and recorded, the third replayed -- the slices are commands of the
+    recorded backward, their learning rate rewritten before the replay --, the fourth NOT armed: recorded again without
+    them, the fifth armed again) parameters, momentum / moments and the bf16 operands equal those of a model stepped
+    the plain way, with the learning rate halved before each of the last three steps."""
     from models.model import create_model
     from utils.utils import create_optimizer
     torch.manual_seed(0)
@@ -156,20 +157,26 @@ def test_optimizer_stepping_inside_the_backward_changes_nothing(name, det_mode):
             loss = F.cross_entropy(score, y)
             opt.zero_grad()
             n0 = len(slices)
+            if step >= 2:
+                opt.param_groups[0]["lr"] *= 0.5  # (a scheduler: the recorded slices must take the new value)
             if armed and step != 3 and step != 0:  # (step 0 sets the flat buffers up: nothing to arm yet)
                 assert opt.arm_backward()
             loss.backward()
-            in_backward = len(slices) - n0
+            in_backward, covered = len(slices) - n0, opt._done
             opt.step()
             torch.cuda.synchronize()
             eng = model.backbone.engine
+            mine = slices[n0:]
             if armed and step in (1, 2, 4):
-                assert in_backward >= 3, in_backward  # layer4's convs are 3.5 - 7 M elements each
-                mine = slices[n0:]
-                assert mine[0][0] == 0 and all(a[1] == b[0] for a, b in zip(mine, mine[1:])) and mine[-1][1] == eng.flat_param.numel()
-                assert all(sl[2] == eng._side.cuda_stream for sl in mine[:-1]) and mine[-1][2] != eng._side.cuda_stream
+                assert covered >= 24 << 20  # layer4 (25 M elements) at least was stepped inside the backward
+                assert mine[-1][0] == covered and mine[-1][1] == eng.flat_param.numel() and mine[-1][2] != eng._side.cuda_stream
+                if step == 2:  # replayed: the slices are commands of the recorded backward, not calls from here
+                    assert in_backward == 0 and len(mine) == 1
+                else:  # made by the hook while the backward ran (step 1: eagerly + recorded; step 4: recorded again)
+                    assert in_backward >= 3 and mine[0][0] == 0 and all(a[1] == b[0] for a, b in zip(mine, mine[1:]))
+                    assert all(sl[2] == eng._side.cuda_stream for sl in mine[:-1])
             else:
-                assert in_backward == 0 and len(slices) - n0 == 1
+                assert in_backward == 0 and covered == 0 and len(mine) == 1
             state = [opt.mom] if name == "sgd" else [opt.exp_avg, opt.exp_avg_sq]
             snaps.append([t.clone() for t in [eng.flat_param, eng.flat_shadow, eng.flat_wd] + state] + [float(loss)])
         runs.append(snaps)

@@ -111,9 +111,10 @@ class R3DEngine:
         self._side = None          # side stream of the weight-gradient launches (see _wgrad)
         self._main = None          # the stream backward was issued on (what a bucket all-reduce must also wait for)
         self.backward_done_cb = None
-        # set by a fused optimizer for ONE backward (optim.arm_backward): hook(params, side_stream or None) -> True when
-        # it launched a slice of its step; not used together with grad_ready_cb
+        # set by a fused optimizer for ONE backward (optim.arm_backward): hook(params, stream or None) -> True when it
+        # launched a slice of its step on `stream`; not used together with grad_ready_cb.  opt_owner: that optimizer
         self.opt_hook = None
+        self.opt_owner = None
         self._stem_scratch = None
         self._tickets = None       # zero int32 words of the fused BatchNorm finalize (see _ticket)
         self._ticket_ix = None
@@ -282,26 +283,30 @@ class R3DEngine:
         """the gradients of `params` are final in stream order from here on (the data-parallel wrapper launches a
         bucket's all-reduce when its last gradient is).  While a backward is being recorded the point is marked in the
         command list as well: its replay stops there and makes the same calls (CommandList.replay_segments)."""
-        if self.grad_ready_cb is None and self.opt_hook is None:
-            return
-        # what the callbacks enqueue is theirs to enqueue again when the step is replayed: it is not recorded
-        rec, capi.RECORDER = capi.RECORDER, None
-        try:
-            cut = False
-            if self.grad_ready_cb is not None:
+        if self.grad_ready_cb is not None:
+            # what the wrapper enqueues is its own to enqueue again when the step is replayed: it is not recorded
+            rec, capi.RECORDER = capi.RECORDER, None
+            try:
+                cut = False
                 for p in params:
                     r = self.grad_ready_cb(p)  # True: it enqueued work (a bucket's all-reduce); None: unknown, assume so
                     cut = cut or r is None or bool(r)
-            else:
-                # side = "side": this point is in the side stream's order (a weight gradient was just issued there), and
-                # everything made final so far, on either stream, precedes it there; "main": the step runs on one
-                # stream; None: a main-stream point while weight gradients are in flight on the side stream
-                stream = self._side if side == "side" else torch.cuda.current_stream() if side == "main" else None
-                cut = bool(self.opt_hook(params, stream))
-        finally:
-            capi.RECORDER = rec
-        if rec is not None:
-            rec.mark((params, side), cut)
+            finally:
+                capi.RECORDER = rec
+            if rec is not None:
+                rec.mark(params, cut)
+        elif self.opt_hook is not None:
+            # side = "side": this point is in the side stream's order (a weight gradient was just issued there), and
+            # everything made final so far, on either stream, precedes it there; "main": the step runs on one stream;
+            # None: a main-stream point while weight gradients are in flight on the side stream.
+            # The optimizer's launches ARE recorded, as commands like any other: their scalars (learning rate, Adam's
+            # step count) are rewritten before each replay (optim._patch), so a replayed backward stays one C call.
+            stream = self._side if side == "side" else torch.cuda.current_stream() if side == "main" else None
+            rec = capi.RECORDER
+            n0 = len(rec.cmds) if rec is not None else 0
+            self.opt_hook(params, stream)
+            if rec is not None:
+                rec.opt_cmds.extend(range(n0, len(rec.cmds)))
 
     def _wgrad(self, d, h, dy, conv):
         """weight gradient of one conv.  Nothing downstream in backward consumes it, so it is issued on a side
@@ -533,19 +538,29 @@ class R3DEngine:
         if eager:
             return self._backward(tape["saved"], df)
         bwd = tape["bwd"]
-        if bwd is not None and bool(bwd.marks) != (self.grad_ready_cb is not None or self.opt_hook is not None):
-            # recorded with / without a data-parallel wrapper (or an optimizer stepping inside the backward), now the
-            # other way round: again
-            bwd = tape["bwd"] = None
+        opt = self.opt_owner if (self.opt_hook is not None and self.grad_ready_cb is None) else None
+        if bwd is not None and bool(bwd.marks) != (self.grad_ready_cb is not None):
+            bwd = tape["bwd"] = None  # recorded with / without a data-parallel wrapper, now the other way round: again
+        if bwd is not None:
+            # ... or with / without an optimizer stepping inside it, or with another optimizer state (its buffers are
+            # named in the commands)
+            ropt = tape.get("opt")
+            if (ropt is None) != (opt is None) or (opt is not None and ropt["key"] != opt._state_key()):
+                bwd = tape["bwd"] = None
         if bwd is not None:
             bwd.patch("dfeat", df.data_ptr())
             self._main = torch.cuda.current_stream()
+            if opt is not None:
+                opt._patch(bwd, ropt["cmds"])
             if bwd.marks:
                 # data parallel: the wrapper's bucket launches come from Python between the kernels -- the list is
                 # replayed in segments that end where a gradient became final while it was recorded
-                bwd.replay_segments(lambda m: self._ready(*m[0], side=m[1]))
+                bwd.replay_segments(lambda params: self._ready(*params))
             else:
                 bwd.replay()
+            if opt is not None:
+                opt._done = ropt["done"]  # (what the recorded slices cover; step() does the rest)
+                self.opt_hook = None
             if self.backward_done_cb is not None:
                 self.backward_done_cb()
             return None
@@ -557,6 +572,7 @@ class R3DEngine:
             ops.TAPE, capi.RECORDER = None, None
         if rec.failed is None and ops.WS_EPOCH == tape["key"][6]:
             tape["bwd"] = rec.freeze({"dfeat": df.data_ptr()})
+            tape["opt"] = None if opt is None else {"cmds": list(rec.opt_cmds), "done": opt._done, "key": opt._state_key()}
         else:
             self._tape = None
         return None

@@ -58,7 +58,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self._flags = [False] * len(eng.grad_ranges)
         self._front = 0
         self._armed_eng = eng
-        eng.opt_hook = self._on_ready
+        eng.opt_hook, eng.opt_owner = self._on_ready, self
         return True
 
     def _on_ready(self, params, stream):
@@ -145,6 +145,17 @@ class FlatAdam(_FlatOptimizer):
             self.exp_avg, self.exp_avg_sq = torch.zeros_like(eng.flat_param), torch.zeros_like(eng.flat_param)
         self.steps += 1
 
+    def _state_key(self):
+        return (self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr())
+
+    def _patch(self, cl, idxs):
+        """this step's scalars into the recorded vc_adam_step commands (ints: ..., n, step, stream; floats: lr, b1, b2, eps, wd)"""
+        g = self.param_groups[0]
+        for i in idxs:
+            c = cl.array[i]
+            c.iarg[6] = self.steps
+            c.farg[0], c.farg[1], c.farg[2], c.farg[3], c.farg[4] = g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]
+
     def _apply(self, eng, a, b):
         g = self.param_groups[0]
         ops.adam_step(eng.flat_param[a:b], eng.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], eng.flat_shadow[a:b],
@@ -190,6 +201,17 @@ class FlatSGD(_FlatOptimizer):
         dev = eng.flat_param.device
         if self.mom is None or self.mom.numel() != eng.flat_param.numel() or self.mom.device != dev:
             self.mom = torch.zeros_like(eng.flat_param) if self.param_groups[0]["momentum"] > 0 else None
+
+    def _state_key(self):
+        return (0 if self.mom is None else self.mom.data_ptr(), self.param_groups[0]["momentum"] > 0)
+
+    def _patch(self, cl, idxs):
+        """this step's scalars into the recorded vc_sgd_step commands (ints: ..., n, nesterov, stream; floats: lr, momentum, wd)"""
+        g = self.param_groups[0]
+        for i in idxs:
+            c = cl.array[i]
+            c.iarg[5] = 1 if g["nesterov"] else 0
+            c.farg[0], c.farg[1], c.farg[2] = g["lr"], g["momentum"], g["weight_decay"]
 
     def _apply(self, eng, a, b):
         g = self.param_groups[0]

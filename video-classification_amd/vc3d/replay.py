@@ -26,6 +26,7 @@ class Recorder:
         self.tag = None     # set by ops around a conv launch: the KernelTimer key of the next command
         self.failed = None
         self.marks = []     # (number of commands recorded before it, payload): points where Python runs between commands
+        self.opt_cmds = []  # indices of the commands a fused optimizer issued inside the backward (engine._ready)
 
     # ---- calls (capi._Lib)
     def add(self, name, fn, argtypes, args, rc):
