@@ -184,10 +184,16 @@ def test_optimizer_stepping_inside_the_backward_changes_nothing(name, det_mode):
         assert a[-1] == b[-1], step
         for u, v in zip(a[:-1], b[:-1]):
             assert torch.equal(u, v), step
+    # armed twice with no backward in between: fine (nothing was stepped yet); after a backward it is refused until step()
+    assert opt.arm_backward() and opt.arm_backward()
+    _, score, _ = model(x)
+    loss = F.cross_entropy(score, y)
+    opt.zero_grad()
+    loss.backward()
     with pytest.raises(Exception, match="again before step"):
         opt.arm_backward()
-        opt.arm_backward()
-    opt.step()  # (clears the armed state)
+    opt.step()
+    assert opt._done == 0 and model.backbone.engine.opt_hook is None
 
 
 def test_flat_adam_matches_torch_adam():

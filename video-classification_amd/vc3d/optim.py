@@ -50,10 +50,11 @@ class _FlatOptimizer(torch.optim.Optimizer):
         eng = self.core.backbone.engine
         if eng.grad_ready_cb is not None or not _IN_BACKWARD or eng.flat_grad is None or eng.flat_shadow is None:
             return False
-        if self._prepared:
+        if self._done:
             raise Vc3dError("%s: arm_backward() again before step() finished the previous one" % type(self).__name__)
-        self._prepare(eng)
-        self._prepared = True
+        if not self._prepared:  # (armed before and no backward came, or it failed before any slice: arm again)
+            self._prepare(eng)
+            self._prepared = True
         self._index = {id(p): i for i, (p, _, _) in enumerate(eng.grad_ranges)}
         self._flags = [False] * len(eng.grad_ranges)
         self._front = 0
