@@ -223,7 +223,7 @@ def main_steps():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 
-    def run(wrap, inject, replay, steps=6):
+    def run(wrap, inject, replay, steps=6, arm=False):
         eng_mod.REPLAY = replay
         cfg, model, crit, opt = build(lr=0.02)
         net = DataParallel3D(model, bucket_mb=4, tail_mb=0.25, grad_dtype="fp32") if wrap else model
@@ -238,7 +238,11 @@ def main_steps():
             opt.zero_grad()
             if inject and wrap:
                 net._ensure().collective = lambda seg: seg.mul_(2)
+            if arm and i > 0:  # the optimizer steps each bucket right behind its all-reduce
+                assert opt.arm_backward(data_parallel=True)
             loss.backward()
+            if arm and i > 0:
+                assert sum(b - a for a, b in opt._applied) >= 24 << 20, opt._applied  # (layer4 at least: 25 of 33 M elements)
             opt.step()
             t = model.backbone.engine._tape
             if t is not None and t["bwd"] is not None:
@@ -252,11 +256,15 @@ def main_steps():
     avg_r_p, avg_r_g, avg_info = run(True, False, True)
     inj_e_p, inj_e_g, _ = run(True, True, False)
     inj_r_p, inj_r_g, inj_info = run(True, True, True)
+    # the optimizer stepping bucket by bucket inside the backward (optim.arm_backward under the wrapper): same result
+    arm_r_p, arm_r_g, _ = run(True, False, True, arm=True)
+    arm_i_p, arm_i_g, _ = run(True, True, False, arm=True)
     eng_mod.REPLAY = True
     print("DDP_STEPS avg_replay_vs_eager=%g avg_vs_plain=%g inject_replay_vs_eager=%g inject_vs_plain_grad=%g "
-          "plain=%s wrapped=%s injected=%s" % (
+          "plain=%s wrapped=%s injected=%s armed_vs_not=%g" % (
               rel(avg_r_p, avg_e_p) + rel(avg_r_g, avg_e_g), rel(avg_r_p, plain_p), rel(inj_r_p, inj_e_p) + rel(inj_r_g, inj_e_g),
-              rel(inj_r_p, plain_p), plain_info, avg_info, inj_info), flush=True)
+              rel(inj_r_p, plain_p), plain_info, avg_info, inj_info,
+              rel(arm_r_p, avg_r_p) + rel(arm_r_g, avg_r_g) + rel(arm_i_p, inj_e_p) + rel(arm_i_g, inj_e_g)), flush=True)
     dist.destroy_process_group()
 
 
@@ -269,7 +277,7 @@ def main_steps2():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    def run(replay, steps=5):
+    def run(replay, steps=5, arm=False):
         eng_mod.REPLAY = replay
         cfg, model, crit, opt = build(lr=0.02)
         net = DataParallel3D(model, bucket_mb=4, tail_mb=0.25, grad_dtype="fp32")
@@ -281,6 +289,8 @@ def main_steps2():
             y = torch.randint(0, 11, (8,), generator=g).cuda()
             loss = crit(net(x)[1], y, None, None)
             opt.zero_grad()
+            if arm and i > 0:
+                assert opt.arm_backward(data_parallel=True)
             loss.backward()
             opt.step()
             t = model.backbone.engine._tape
@@ -294,10 +304,11 @@ def main_steps2():
 
     pe, same_e, _ = run(False)
     pr, same_r, info = run(True)
+    pa, same_a, _ = run(True, arm=True)  # the optimizer stepping each bucket behind its all-reduce
     eng_mod.REPLAY = True
     if rank == 0:
-        print("DDP_STEPS2 ranks_agree_eager=%d ranks_agree_replay=%d replay_vs_eager=%g recorded=%s" % (
-            int(same_e), int(same_r), rel(pr, pe), info), flush=True)
+        print("DDP_STEPS2 ranks_agree_eager=%d ranks_agree_replay=%d replay_vs_eager=%g recorded=%s armed_agree=%d armed_vs_eager=%g" % (
+            int(same_e), int(same_r), rel(pr, pe), info, int(same_a), rel(pa, pe)), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

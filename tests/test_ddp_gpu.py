@@ -116,10 +116,11 @@ def test_data_parallel_backward_replays_in_segments():
     assert r.returncode == 0, r.stderr[-3000:]
     m = re.search(r"DDP_STEPS avg_replay_vs_eager=(\S+) avg_vs_plain=(\S+) inject_replay_vs_eager=(\S+) "
                   r"inject_vs_plain_grad=(\S+) plain=\((\d+), (\d+), (\d+), (\d+)\) wrapped=\((\d+), (\d+), (\d+), (\d+)\) "
-                  r"injected=\((\d+), (\d+), (\d+), (\d+)\)", r.stdout)
+                  r"injected=\((\d+), (\d+), (\d+), (\d+)\) armed_vs_not=(\S+)", r.stdout)
     assert m, r.stdout[-2000:]
     print(m.group(0))
     assert float(m.group(1)) == 0.0 and float(m.group(3)) == 0.0
+    assert float(m.group(17)) == 0.0  # optimizer.arm_backward(): each bucket stepped behind its all-reduce, same bits
     assert float(m.group(2)) <= 1e-7
     assert float(m.group(4)) > 1e-3
     plain, wrapped, injected = (tuple(int(m.group(i + j)) for j in range(4)) for i in (5, 9, 13))
@@ -139,11 +140,12 @@ def test_two_ranks_train_several_recorded_steps_in_lockstep():
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_worker.py"), "steps2"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
-    m = re.search(r"DDP_STEPS2 ranks_agree_eager=(\d) ranks_agree_replay=(\d) replay_vs_eager=(\S+) recorded=\((\d+), (\d+)\)",
-                  r.stdout)
+    m = re.search(r"DDP_STEPS2 ranks_agree_eager=(\d) ranks_agree_replay=(\d) replay_vs_eager=(\S+) recorded=\((\d+), (\d+)\) "
+                  r"armed_agree=(\d) armed_vs_eager=(\S+)", r.stdout)
     assert m, r.stdout[-2000:]
     print(m.group(0))
     assert m.group(1) == "1" and m.group(2) == "1" and float(m.group(3)) == 0.0
+    assert m.group(6) == "1" and float(m.group(7)) == 0.0  # with the optimizer stepping bucket by bucket (arm_backward)
     assert int(m.group(4)) >= 2 and int(m.group(5)) >= 20
 
 

@@ -54,6 +54,9 @@ class GradBucketReducer:
             raise ValueError("grad_dtype must be 'fp32' or 'bf16'")
         self.grad_dtype = grad_dtype
         self.collective = None  # test hook: callable(slice) run on the communication stream in place of the all-reduce
+        # callable(start, end) run on the communication stream right behind a bucket's all-reduce: a fused optimizer that
+        # steps the bucket's parameters while the rest of the backward runs (optim.arm_backward)
+        self.after_reduce = None
         self.enabled = True     # False inside DataParallel3D.no_sync()
         esz = flat.element_size()
         # cut from the end so that the bucket that finishes last (exposed at the end of backward) is the small one
@@ -135,9 +138,13 @@ class GradBucketReducer:
                 for ev in evs:
                     self.comm_stream.wait_event(ev)
                 self._reduce(seg, start, end)
+                if self.after_reduce is not None:
+                    self.after_reduce(start, end)
             self.works.append(b)
         else:
             self._reduce(seg, start, end)
+            if self.after_reduce is not None:
+                self.after_reduce(start, end)
 
     def finish(self):
         """flush buckets that never filled (unused parameters), then join the side stream."""
@@ -183,6 +190,7 @@ class DataParallel3D(torch.nn.Module):
         # through train.py, or VC_DDP_GRAD_DTYPE=bf16.
         self.grad_dtype = grad_dtype or os.environ.get("VC_DDP_GRAD_DTYPE", "fp32")
         self.reducer = None
+        self.after_reduce = None  # see GradBucketReducer.after_reduce (set per step by optim.arm_backward)
         self._extras_queued = False
         self._sync = True
         broadcast_module(model, 0, group)
@@ -203,12 +211,12 @@ class DataParallel3D(torch.nn.Module):
 
     def _on_ready(self, p):
         r = self._ensure()
-        r.enabled = self._sync
+        r.enabled, r.after_reduce = self._sync, self.after_reduce
         return r.on_ready(id(p))
 
     def _on_done(self):
         r = self._ensure()
-        r.enabled = self._sync
+        r.enabled, r.after_reduce = self._sync, self.after_reduce
         r.finish()
         # Parameters that live outside the engine's flat buffer -- the recurrent head of MODEL.USE_LSTM (LSTMCell,
         # act_head, clf_haed, crit_head: reference model.py:18-25, wrapped by DataParallel as part of the whole model at

@@ -27,6 +27,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.core = core
         self._done = 0  # elements of the flat buffers that slices inside the backward have stepped already
         self._prepared = False  # arm_backward() has made this step's state (momentum buffers, Adam's step count)
+        self._applied = []  # (data parallel) the buckets stepped behind their all-reduce: [(start, end)]
         super().__init__(list(core.parameters()), defaults)
 
     # ---- stepping inside the backward
@@ -42,15 +43,26 @@ class _FlatOptimizer(torch.optim.Optimizer):
     # elements: a slice launch costs what any launch costs; 3 M elements are ~10 us of step (VC_OPT_MIN_SLICE overrides)
     MIN_SLICE = int(os.environ.get("VC_OPT_MIN_SLICE", 3 << 20))
 
-    def arm_backward(self):
+    def arm_backward(self, data_parallel=False):
         """The NEXT backward computes this step's complete gradients (no accumulation over several backwards, nothing
         edits the gradients before step()): parts of step() may run inside it.  Without this call step() does all the
-        work, as before.  Ignored under the data-parallel wrapper (its buckets own the ready points) and when
-        VC_OPT_IN_BACKWARD=0."""
+        work, as before.  Under the data-parallel wrapper the call is ignored unless data_parallel=True: the slices are
+        then its buckets, each stepped on the communication stream behind its all-reduce -- correct (tests/test_ddp_gpu.py)
+        but not the default: on one rank with the buckets forced it measured 4.80 against 4.79 ms, and on several GPUs,
+        where a slice delays the next bucket's all-reduce on that stream, it has not been measured at all.
+        Ignored inside DataParallel3D.no_sync() and when VC_OPT_IN_BACKWARD=0."""
         eng = self.core.backbone.engine
-        if eng.grad_ready_cb is not None or not _IN_BACKWARD or eng.flat_grad is None or eng.flat_shadow is None:
+        if not _IN_BACKWARD or eng.flat_grad is None or eng.flat_shadow is None:
             return False
-        if self._done:
+        dp = None
+        if eng.grad_ready_cb is not None:
+            # under the data-parallel wrapper the ready points are its buckets': the slices are the buckets themselves
+            # (contiguous pieces of the flat buffers, in order), stepped on its communication stream right behind each
+            # bucket's all-reduce
+            dp = getattr(eng.grad_ready_cb, "__self__", None)
+            if not data_parallel or dp is None or not hasattr(dp, "after_reduce") or not getattr(dp, "_sync", True):
+                return False
+        if self._done or self._applied:
             raise Vc3dError("%s: arm_backward() again before step() finished the previous one" % type(self).__name__)
         if not self._prepared:  # (armed before and no backward came, or it failed before any slice: arm again)
             self._prepare(eng)
@@ -58,9 +70,17 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self._index = {id(p): i for i, (p, _, _) in enumerate(eng.grad_ranges)}
         self._flags = [False] * len(eng.grad_ranges)
         self._front = 0
-        self._armed_eng = eng
+        self._armed_eng, self._armed_dp = eng, dp
+        if dp is not None:
+            dp.after_reduce = self._after_reduce
+            return True
         eng.opt_hook, eng.opt_owner = self._on_ready, self
         return True
+
+    def _after_reduce(self, start, end):
+        """(data parallel) bucket [start, end) of the flat gradient has been averaged, in the current stream's order"""
+        self._apply(self._armed_eng, start, end)
+        self._applied.append((start, end))  # (buckets need not finish in order: step() takes what is missing)
 
     def _on_ready(self, params, stream):
         eng = self._armed_eng
@@ -84,12 +104,17 @@ class _FlatOptimizer(torch.optim.Optimizer):
     def _finish(self, eng):
         """step(): the part of the flat buffers that no slice has covered"""
         eng.opt_hook = None
+        if getattr(self, "_armed_dp", None) is not None:
+            self._armed_dp.after_reduce = None  # (its slices sit on the communication stream, joined when backward ended)
+            self._armed_dp = None
         if not self._prepared:
             self._prepare(eng)
-        n = eng.flat_param.numel()
-        if self._done < n:
-            self._apply(eng, self._done, n)
-        self._done, self._prepared = 0, False
+        pos, n = 0, eng.flat_param.numel()
+        for a, b in sorted([(0, self._done)] + self._applied) + [(n, n)]:
+            if a > pos:
+                self._apply(eng, pos, a)
+            pos = max(pos, b)
+        self._done, self._prepared, self._applied = 0, False, []
 
     def _flat(self):
         """the engine with flat gradients / weights set up and every parameter's gradient inside the flat buffer"""
@@ -134,7 +159,7 @@ class FlatAdam(_FlatOptimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if closure is not None and self._done:
+        if closure is not None and (self._done or self._applied):
             raise Vc3dError("FlatAdam: a closure cannot be combined with arm_backward()")
         eng = self._flat()
         self._finish(eng)
@@ -191,7 +216,7 @@ class FlatSGD(_FlatOptimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if closure is not None and self._done:
+        if closure is not None and (self._done or self._applied):
             raise Vc3dError("FlatSGD: a closure cannot be combined with arm_backward()")
         eng = self._flat()
         self._finish(eng)
