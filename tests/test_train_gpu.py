@@ -196,6 +196,47 @@ def test_optimizer_stepping_inside_the_backward_changes_nothing(name, det_mode):
     assert opt._done == 0 and model.backbone.engine.opt_hook is None
 
 
+def test_zero_grad_clears_the_flat_gradient_early_and_safely(det_mode, monkeypatch):
+    """FlatSGD.zero_grad() clears the flat gradient buffer on the engine's side stream behind the step that last read it,
+    and the backward only waits for that.  Same gradients and parameters, bit for bit (deterministic sums), as with the
+    clear inside the backward -- also when a step is SKIPPED (backward, zero_grad, no step(): that backward's writes are
+    not behind the recorded event, so the early clear must stand down) and when zero_grad() comes before the forward."""
+    from models.model import create_model
+    from utils.utils import create_optimizer
+    from vc3d import optim
+    cfg = make_config(18, 7, OPTIMIZER="sgd", LR=0.05, MOMENTUM=0.9, WD=1e-3, NESTEROV=False)
+    x = torch.randn(4, 3, 4, 32, 32).cuda()
+    y = torch.randint(0, 7, (4,)).cuda()
+    runs = []
+    for early in (False, True):
+        monkeypatch.setattr(optim, "_EARLY_ZERO", early)
+        torch.manual_seed(1)
+        model = create_model(cfg, True).cuda().train()
+        opt = create_optimizer(cfg, model)
+        eng = model.backbone.engine
+        snaps, used = [], 0
+        for step in range(6):
+            if step == 4:
+                opt.zero_grad()  # before the forward this time
+            _, score, _ = model(x * (1 + 0.1 * step))
+            loss = F.cross_entropy(score, y)
+            if step != 4:
+                opt.zero_grad()
+            used += eng._zero_ev is not None
+            loss.backward()
+            assert eng._zero_ev is None
+            snaps.append(eng.flat_grad.clone())
+            if step != 2:  # step 2 is skipped: its gradients are dropped by the next zero_grad()
+                opt.step()
+            snaps.append(eng.flat_param.clone())
+        torch.cuda.synchronize()
+        # early: used from the second step on, except right after the skipped step
+        assert used == (4 if early else 0), used
+        runs.append(snaps)
+    for i, (a, b) in enumerate(zip(*runs)):
+        assert torch.equal(a, b), i
+
+
 def test_flat_adam_matches_torch_adam():
     """create_optimizer's 'adam' (the reference's default optimizer, config.py:43, utils.py:30-33) on the GPU is the
     fused flat step (vc_adam_step): against torch.optim.Adam(lr) on the same gradients, three steps (both moments and

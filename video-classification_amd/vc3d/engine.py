@@ -115,6 +115,8 @@ class R3DEngine:
         # launched a slice of its step on `stream`; not used together with grad_ready_cb.  opt_owner: that optimizer
         self.opt_hook = None
         self.opt_owner = None
+        self._zero_ev = None  # recorded behind a clear of flat_grad on the side stream (optim.zero_grad)
+        self._bwd_serial = 0  # backward passes run so far
         self._stem_scratch = None
         self._tickets = None       # zero int32 words of the fused BatchNorm finalize (see _ticket)
         self._ticket_ix = None
@@ -257,7 +259,11 @@ class R3DEngine:
             if p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == v.stride():
                 fresh = False
         if fresh:
-            self.flat_grad.zero_()
+            if self._zero_ev is not None:  # cleared on the side stream by the optimizer's zero_grad(): wait for that
+                torch.cuda.current_stream().wait_event(self._zero_ev)
+            else:
+                self.flat_grad.zero_()
+        self._zero_ev = None
         for p in self.plist:
             v = self.grad_views[id(p)]
             if not p.requires_grad:
@@ -609,6 +615,7 @@ class R3DEngine:
             raise
 
     def backward(self, saved, dfeat):
+        self._bwd_serial += 1
         try:
             if isinstance(saved, _TapeStep):
                 return self._backward_recorded(saved, dfeat)

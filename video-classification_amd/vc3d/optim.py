@@ -15,6 +15,7 @@ from . import ops
 from .capi import Vc3dError
 
 _IN_BACKWARD = os.environ.get("VC_OPT_IN_BACKWARD", "1") != "0"
+_EARLY_ZERO = os.environ.get("VC_NO_EARLY_ZERO") is None
 
 
 class _FlatOptimizer(torch.optim.Optimizer):
@@ -28,6 +29,8 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self._done = 0  # elements of the flat buffers that slices inside the backward have stepped already
         self._prepared = False  # arm_backward() has made this step's state (momentum buffers, Adam's step count)
         self._applied = []  # (data parallel) the buckets stepped behind their all-reduce: [(start, end)]
+        self._consumed_ev = None  # recorded when step() has issued the last reader of the gradients
+        self._consumed_serial = -1  # the engine's backward count at that moment
         super().__init__(list(core.parameters()), defaults)
 
     # ---- stepping inside the backward
@@ -115,6 +118,31 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 self._apply(eng, pos, a)
             pos = max(pos, b)
         self._done, self._prepared, self._applied = 0, False, []
+        if eng.flat_grad.is_cuda:  # everything that reads this step's gradients has been issued: zero_grad() may clear them behind it
+            self._consumed_ev = torch.cuda.Event()
+            self._consumed_ev.record()
+            self._consumed_serial = eng._bwd_serial
+
+    def zero_grad(self, set_to_none=True):
+        """torch's zero_grad; with set_to_none (the default) the flat gradient buffer is cleared right here on the
+        engine's side stream -- behind the step that last read it -- instead of on the backward's own stream when it
+        starts: 18 us (133 MB) that otherwise sit between the loss and the first backward launch."""
+        super().zero_grad(set_to_none)
+        eng = self.core.backbone.engine
+        ev = self._consumed_ev
+        if not (set_to_none and _EARLY_ZERO and ev is not None and eng.flat_grad is not None and eng.flat_grad.is_cuda):
+            return
+        if any(p.grad is not None for p in eng.plist):  # (a parameter outside this optimizer's groups kept its gradient)
+            return
+        if eng._bwd_serial != self._consumed_serial:  # a backward ran since step(): its writes are not behind `ev`
+            return
+        if eng._side is None or eng._side.device != eng.flat_grad.device:
+            eng._side = torch.cuda.Stream(device=eng.flat_grad.device)
+        with torch.cuda.stream(eng._side):
+            eng._side.wait_event(ev)
+            eng.flat_grad.zero_()
+            eng._zero_ev = torch.cuda.Event()
+            eng._zero_ev.record()
 
     def _flat(self):
         """the engine with flat gradients / weights set up and every parameter's gradient inside the flat buffer"""
