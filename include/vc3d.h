@@ -275,6 +275,14 @@ int vc_linear_bwd(const float* dlogits, const float* feat, const float* W, float
                   float* dW /* += nullable */, float* db /* += nullable */, int32_t N, int32_t F,
                   int32_t K, void* stream);
 
+/* ---- Cross-entropy of the class scores (fp32), the first term of the reference's Loss (lib/core/loss.py:10,25:
+ * nn.CrossEntropyLoss, mean reduction): loss[0] = mean_n (logsumexp(logits[n]) - logits[n][labels[n]]) and, when dlogits
+ * is given, d loss / d logits = (softmax - onehot) / N, in one launch instead of torch's chain of log-softmax / NLL /
+ * fill / NLL-backward / softmax-backward launches between the forward and the backward.  K <= 1024 (a row lives in
+ * registers; more is refused).  A label outside [0, K) makes the loss NaN (torch raises; that needs the labels on the host). */
+int vc_softmax_ce(const float* logits, const int64_t* labels, float* loss, float* dlogits /* nullable */, int32_t N,
+                  int32_t K, void* stream);
+
 /* ---- LSTM cell.  Replaces nn.LSTMCell at reference lib/models/lstm.py:16,25-27.  The cell's two
  * GEMMs, gates[N][4H] = [x h] [W_ih W_hh]^T, are a 1x1x1 conv over N positions (vc_conv3d_fwd / _dgrad / _wgrad with
  * T = H = W = 1, Ci = Fin + H, Co = 4H; bf16 MFMA).  These two calls are the element-wise rest, one pass each way.

@@ -356,6 +356,50 @@ def test_avgpool_linear(N, C, S, K):
     assert rel_l2(din.float().cpu(), ref) <= TOL_BF16
 
 
+@pytest.mark.parametrize("N,K", [(64, 101), (64, 400), (3, 7), (5, 1000), (130, 64), (9, 1024)])
+def test_cross_entropy_value_and_gradient_in_one_launch(N, K):
+    """vc_softmax_ce (what Loss uses for the class scores on the GPU) against F.cross_entropy in fp64: the mean loss and
+    d loss / d logits, through autograd with a non-unit upstream gradient; a label outside [0, K) gives NaN; Loss itself
+    (reference loss.py:25-30) with and without the actor / critic terms equals its torch-only form."""
+    _need_gpu()
+    from vc3d.autograd import cross_entropy
+    from core.loss import Loss
+    import core.loss as loss_mod
+    from helpers import make_config
+    g = torch.Generator().manual_seed(N * K)
+    logits = (torch.randn(N, K, generator=g) * 4).cuda().requires_grad_(True)
+    y = torch.randint(0, K, (N,), generator=g).cuda()
+    ref_in = logits.detach().double().requires_grad_(True)
+    ref = F.cross_entropy(ref_in, y)
+    (ref * 1.7).backward()
+    out = cross_entropy(logits, y)
+    (out * 1.7).backward()
+    torch.cuda.synchronize()
+    assert out.shape == () and abs(float(out) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert rel_l2(logits.grad.cpu(), ref_in.grad.float().cpu()) <= 1e-5
+    with torch.no_grad():
+        assert abs(float(cross_entropy(logits, y)) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+        bad = y.clone()
+        bad[0] = K
+        assert torch.isnan(cross_entropy(logits, bad))
+    cfg = make_config(18, K)
+    crit = Loss(cfg).cuda()
+    lp, adv = torch.randn(N, 1, generator=g).cuda().requires_grad_(True), torch.randn(N, 1, generator=g).cuda().requires_grad_(True)
+    for extra in ((None, None), (lp, adv)):
+        vals = []
+        for fused in (True, False):
+            loss_mod._FUSED_CE = fused
+            try:
+                l2 = logits.detach().clone().requires_grad_(True)
+                v = crit(l2, y, *extra)
+                v.backward()
+                vals.append((float(v), l2.grad.clone()))
+            finally:
+                loss_mod._FUSED_CE = True
+        assert abs(vals[0][0] - vals[1][0]) <= 1e-5 * max(1.0, abs(vals[1][0]))
+        assert rel_l2(vals[0][1].cpu(), vals[1][1].cpu()) <= 1e-5
+
+
 def test_layout_roundtrip_and_add():
     _need_gpu()
     from vc3d import ops

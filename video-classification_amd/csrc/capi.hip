@@ -1191,6 +1191,11 @@ int vc_linear_bwd(const float* dlogits, const float* feat, const float* W, float
     return vc_ew_linear_bwd(dlogits, feat, W, dfeat, dW, db, N, F, K, S(stream));
 }
 
+int vc_softmax_ce(const float* logits, const int64_t* labels, float* loss, float* dlogits, int32_t N, int32_t K, void* stream) {
+    VC_REQUIRE(logits && labels && loss && N > 0 && K > 0, "softmax_ce: bad arguments");
+    return vc_ew_softmax_ce(logits, (const long long*)labels, loss, dlogits, N, K, S(stream));
+}
+
 /* ------------------------------------------------------------------ LSTM cell (element-wise half) */
 int vc_lstm_pointwise_fwd(const void* gates, const float* b_ih, const float* b_hh, const float* c_prev, float* h, float* c,
                           void* h_bf16, float* saved, int32_t N, int32_t H, void* stream) {

@@ -44,6 +44,7 @@ int vc_ew_maxpool_fwd(const void* y, const float* params, void* out, uint8_t* id
 int vc_ew_maxpool_bwd(const void* dout, const uint8_t* idx, void* din, const VcPoolGeom& g, hipStream_t s);
 int vc_ew_avgpool_fwd(const void* in, float* out, int N, int S, int C, hipStream_t s);
 int vc_ew_avgpool_bwd(const float* dfeat, void* din, int N, int S, int C, hipStream_t s);
+int vc_ew_softmax_ce(const float* logits, const long long* y, float* loss, float* dlogits, int N, int K, hipStream_t s);
 int vc_ew_linear_fwd(const float* feat, const float* W, const float* bias, float* out, int N, int F, int K,
                      hipStream_t s);
 int vc_ew_linear_bwd(const float* dlog, const float* feat, const float* W, float* dfeat, float* dW, float* db, int N,

@@ -1560,6 +1560,74 @@ __global__ __launch_bounds__(256) void pack_dgrad_batched_kernel(const bf16* __r
     o[1] = b;
 }
 
+// ------------------------------------------------------------------ cross-entropy of the class scores
+// loss = mean_n (logsumexp(logits[n]) - logits[n][y[n]]) and its gradient d loss / d logits = (softmax - onehot) / N in ONE
+// launch of one workgroup (N x K is 64 x 101 .. 400: nothing to parallelise over, a chain of four to seven dependent tiny
+// launches to save).  16 waves; a wave takes R rows at a time with all their loads issued before the first use (a row
+// at a time is a chain of ~2 us round trips), a row lives in registers (K <= 64 KPL); fixed summation order; labels
+// outside [0, K) leave NaN in the loss (torch raises for them, which needs the host to see the labels).
+template <int KPL, int R>  // K <= 64 KPL; R rows per wave in flight
+__global__ __launch_bounds__(1024) void softmax_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ y,
+                                                          float* __restrict__ loss, float* __restrict__ dlogits, int N, int K) {
+    __shared__ float sm[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float part = 0.f;
+    for (int n0 = wave * R; n0 < N; n0 += 16 * R) {
+        float v[R][KPL];
+        long long t[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = n0 + r;
+            t[r] = n < N ? y[n] : 0;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                const int k = lane + i * 64;
+                v[r][i] = (n < N && k < K) ? logits[(size_t)n * K + k] : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = n0 + r;
+            if (n >= N) break;  // (wave-uniform)
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) m = fmaxf(m, v[r][i]);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            float e = 0.f, zt = 0.f;
+            const bool ok = t[r] >= 0 && t[r] < K;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                if (lane + i * 64 == t[r]) zt = v[r][i];
+                v[r][i] = expf(v[r][i] - m);  // (exp(-inf) = 0 for the padding)
+                e += v[r][i];
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                e += __shfl_xor(e, o, 64);
+                zt += __shfl_xor(zt, o, 64);
+            }
+            part += ok ? (m + logf(e)) - zt : NAN;
+            if (dlogits != nullptr) {
+                const float inv = 1.f / e, invn = 1.f / (float)N;
+#pragma unroll
+                for (int i = 0; i < KPL; ++i) {
+                    const int k = lane + i * 64;
+                    if (k < K) dlogits[(size_t)n * K + k] = (v[r][i] * inv - (k == t[r] ? 1.f : 0.f)) * invn;
+                }
+            }
+        }
+    }
+    if (lane == 0) sm[wave] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += sm[w];
+        loss[0] = s / (float)N;
+    }
+}
+
 inline int grid_for(long n, int block = 256, int cap = 256 * 16) {
     long g = (n + block - 1) / block;
     if (g > cap) g = cap;
@@ -1800,6 +1868,16 @@ int vc_ew_linear_fwd(const float* feat, const float* W, const float* bias, float
     } else {
         const int waves = ((N + 3) / 4) * ((K + 3) / 4);
         VC_LAUNCH(linear_fwd_tiled_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, feat, W, bias, out, N, F, K);
+    }
+    return VC_CHECK_LAUNCH();
+}
+int vc_ew_softmax_ce(const float* logits, const long long* y, float* loss, float* dlogits, int N, int K, hipStream_t s) {
+    if (K <= 128) VC_LAUNCH((softmax_ce_kernel<2, 4>), dim3(1), dim3(1024), 0, s, logits, y, loss, dlogits, N, K);
+    else if (K <= 512) VC_LAUNCH((softmax_ce_kernel<8, 4>), dim3(1), dim3(1024), 0, s, logits, y, loss, dlogits, N, K);
+    else if (K <= 1024) VC_LAUNCH((softmax_ce_kernel<16, 2>), dim3(1), dim3(1024), 0, s, logits, y, loss, dlogits, N, K);
+    else {
+        vc_set_error("softmax_ce: K=%d classes (at most 1024: a row lives in registers)", K);
+        return -2;
     }
     return VC_CHECK_LAUNCH();
 }

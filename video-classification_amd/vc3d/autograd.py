@@ -84,3 +84,25 @@ class _LinearFn(torch.autograd.Function):
 
 def linear_apply(feat, W, b, engine=None):
     return _LinearFn.apply(feat, W, b, engine)
+
+
+class _SoftmaxCEFn(torch.autograd.Function):
+    """mean cross-entropy with its gradient made in the forward's launch (ops.softmax_ce)"""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, dlog = ops.softmax_ce(logits.contiguous(), labels.contiguous(), want_grad=ctx.needs_input_grad[0])
+        ctx.save_for_backward(dlog)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        return dlog * g, None
+
+
+def cross_entropy(logits, labels):
+    """F.cross_entropy(logits, labels) (mean reduction, class-index targets) for fp32 logits [N][K] on the GPU: one launch
+    forward, one multiply backward."""
+    return _SoftmaxCEFn.apply(logits, labels)
+

@@ -121,6 +121,7 @@ PROTOTYPES = {
     "vc_bn_bwd_apply_pooled": [_PD, _P, _P, _P, _P, _P, _P, _P],
     "vc_gavgpool_fwd": [_P, _P, _I, _I, _I, _P],
     "vc_gavgpool_bwd": [_P, _P, _I, _I, _I, _P],
+    "vc_softmax_ce": [_P, _P, _P, _P, _I, _I, _P],
     "vc_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vc_linear_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vc_lstm_pointwise_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],

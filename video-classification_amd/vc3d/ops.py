@@ -637,6 +637,18 @@ def gavgpool_bwd(dfeat, N, S, Cn, shape):
     return din
 
 
+def softmax_ce(logits, labels, want_grad=True):
+    """mean cross-entropy of fp32 logits [N][K] against int64 labels [N] and its gradient (softmax - onehot) / N, one
+    launch (vc_softmax_ce) -> (loss [1], dlogits [N][K] or None)"""
+    N, K = logits.shape
+    _chk(logits, F32, N * K, "logits")
+    _chk(labels, torch.int64, N, "labels")
+    loss = _empty(1, dtype=F32, device=logits.device)
+    dlog = _empty(N, K, dtype=F32, device=logits.device) if want_grad else None
+    check(lib.vc_softmax_ce(ptr(logits), ptr(labels), ptr(loss), ptr(dlog), N, K, cur_stream()), "vc_softmax_ce")
+    return loss, dlog
+
+
 def linear_fwd(feat, W, bias):
     N, Fd = feat.shape
     K = W.shape[0]
