@@ -49,8 +49,11 @@ class VedioClfNet(nn.Module):
         eng.head_params = (self.clf_haed.weight, self.clf_haed.bias)
         feat = self.backbone(x)
         score = vc3d.linear_apply(feat, self.clf_haed.weight, self.clf_haed.bias, eng)
-        zeros = torch.zeros(score.shape[0], 1, dtype=score.dtype, device=score.device)
-        return zeros, score, zeros
+        # (one constant tensor per batch size, not a fill launch per step between the head and the loss: nothing writes it)
+        key = (score.shape[0], score.dtype, score.device)
+        if getattr(self, "_zeros_key", None) != key:
+            self._zeros_key, self._zeros = key, torch.zeros(score.shape[0], 1, dtype=score.dtype, device=score.device)
+        return self._zeros, score, self._zeros
 
     def init_weights(self):
         """the backbone loads its checkpoint in getBackbone; the head keeps nn.Linear's default."""
