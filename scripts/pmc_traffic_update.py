@@ -4,7 +4,7 @@ scripts/pmc_summary.py.  Only kernels that run ONE launch geometry in the profil
 per-kernel means): the stem kernels and layer1's halo kernel (its 4 forward + 4 data-gradient launches share one
 geometry and one traffic pattern).
 
-  python scripts/pmc_traffic_update.py profiles/r03_v4_pmc_per_kernel.csv"""
+  python scripts/pmc_traffic_update.py profiles/r03_v5_pmc_per_kernel.csv"""
 import csv
 import json
 import os
